@@ -1,0 +1,177 @@
+/* vvtts.h -- C ABI of the MI355X-native VietVoice-TTS synthesis hot path (libvvtts_hip.so).
+ *
+ * The reference has no FFI: its hot path is three onnxruntime sessions driven from Python
+ *   preprocess : vietvoicetts/core/tts_engine.py:133-146  (sessions['preprocess'].run)
+ *   transformer: vietvoicetts/core/tts_engine.py:148-174  (sessions['transformer'].run, 31 calls)
+ *   decode     : vietvoicetts/core/tts_engine.py:176-187  (sessions['decode'].run)
+ * created in vietvoicetts/core/model.py:65-129.  This header is what a binding for that path
+ * would bind instead (INTEGRATION.md shows the ctypes stub): plain pointers and sizes, no torch
+ * types, every call returns 0 or a negative errno-style code, the message is read with
+ * vv_last_error(); nothing aborts or throws across the ABI.  All pointers named *device* are
+ * HBM addresses on the context's GPU; `stream` is a hipStream_t passed as void*.
+ * One context per GPU; calls on one context must be serialised by the caller
+ * (reference threading: vietvoicetts/api/tts_engine.py:64-87).
+ */
+#ifndef VVTTS_H
+#define VVTTS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VV_DTYPE_F32 0
+#define VV_DTYPE_BF16 1
+#define VV_MAX_UP 8
+#define VV_MAX_RES 4
+
+/* activation codes (gemm epilogue) */
+#define VV_ACT_NONE_ 0
+#define VV_ACT_GELU_TANH_ 1
+#define VV_ACT_GELU_ERF_ 2
+#define VV_ACT_SILU_ 3
+#define VV_ACT_MISH_ 4
+/* gemm epilogue modes */
+#define VV_EPI_STORE 0     /* C = act(A W^T + bias)                         */
+#define VV_EPI_QKV_ROPE 1  /* C = rope(A W^T + bias) on the q and k columns */
+#define VV_EPI_GATE_RES 2  /* C += gate * (A W^T + bias)   (fp32 residual)  */
+
+typedef struct vv_ctx vv_ctx;
+
+/* Architecture constants (the reference hides them in the ONNX graphs). */
+typedef struct vv_model_cfg {
+    int32_t n_mel, n_fft, win_length, hop_length;
+    int32_t dim, depth, heads, head_dim, ff_mult;
+    int32_t text_dim, text_layers, text_conv_k, text_ff_mult, vocab_rows;
+    int32_t pos_conv_k, pos_conv_groups, time_freq_dim;
+    float cfg_strength;
+    int32_t voc_pre_ch, voc_pre_k, voc_post_k;
+    int32_t voc_n_up, voc_up_rates[VV_MAX_UP], voc_up_kernels[VV_MAX_UP];
+    int32_t voc_n_res, voc_res_kernels[VV_MAX_RES];
+    int32_t voc_n_dil, voc_res_dilations[VV_MAX_RES];
+    float voc_lrelu;
+    int32_t max_pos; /* rows of the rope / text position tables */
+} vv_model_cfg;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* replaces onnxruntime.InferenceSession creation, core/model.py:96-102 */
+int vv_create(vv_ctx** out, int device, const vv_model_cfg* cfg, int acoustic_dtype);
+void vv_destroy(vv_ctx* ctx);
+const char* vv_last_error(const vv_ctx* ctx);   /* ctx may be NULL: last create error */
+const char* vv_version(void);
+
+/* Bind one named tensor of the (already uploaded) flat weight buffer.  Layouts: DESIGN.md 3. */
+int vv_bind_weight(vv_ctx* ctx, const char* name, const void* device_ptr, uint64_t bytes);
+/* Verify every tensor the three stages need is bound (names listed in the error if not). */
+int vv_finalize_weights(vv_ctx* ctx);
+
+/* ODE time grid: sinus[n_steps][time_freq_dim] (host), dt[n_steps] (host).  Runs the time MLP and
+ * every block's AdaLN projection once on the GPU and keeps the modulation tables in HBM. */
+int vv_set_time_grid(vv_ctx* ctx, const float* sinus_host, const float* dt_host, int n_steps, void* stream);
+
+/* ---- the three stages (device-resident, batched) ------------------------------------------ */
+/* replaces sessions['preprocess'].run, core/tts_engine.py:133-146.
+ * audio [B][ld_audio] int16, audio_len[B], text_ids [B][ld_text] int32, text_len[B], seq_len[B]
+ * (= max_duration per item, frames), N = padded frame count (>= every seq_len).
+ * Outputs: cat_mel_text, cat_mel_text_drop [B][N][n_mel+text_dim] f32, ref_signal_len[B] int32.
+ * (noise is supplied by the caller; the rope tables are slices of the bound constant tables.) */
+int vv_preprocess(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len,
+                  const int32_t* audio_len, const int32_t* text_ids, int ld_text, const int32_t* text_len,
+                  const int32_t* seq_len, float* cat_mel_text, float* cat_mel_text_drop,
+                  int32_t* ref_signal_len, void* stream);
+
+/* replaces the loop over sessions['transformer'].run, core/tts_engine.py:148-174: n_steps Euler
+ * steps of the flow ODE starting at step index step0, state x [B][N][n_mel] f32 updated in HBM.
+ * rope tables are [>=N][head_dim] f32 (q tables carry the softmax scale). */
+int vv_transformer_steps(vv_ctx* ctx, int B, int N, const int32_t* seq_len, float* x, const float* cat_mel_text,
+                         const float* cat_mel_text_drop, const float* rope_cos_q, const float* rope_sin_q,
+                         const float* rope_cos_k, const float* rope_sin_k, int step0, int n_steps, void* stream);
+
+/* replaces sessions['decode'].run, core/tts_engine.py:176-187: frames [ref_len, seq_len) of x ->
+ * vocoder -> int16 PCM.  pcm [B][ld_pcm], ld_pcm >= t_gen_max*hop; pcm_len[B] = samples per item.
+ * wave_f32 (optional, [B][t_gen_max*hop]) receives the pre-quantisation waveform. */
+int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
+              int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream);
+
+/* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
+#define VV_PROF_GEMM 0
+#define VV_PROF_ATTN 1
+#define VV_PROF_NORM 2
+#define VV_PROF_POSCONV 3
+#define VV_PROF_ELEMWISE 4
+#define VV_PROF_VOC_CONV 5
+#define VV_PROF_VOC_POST 6
+#define VV_PROF_MEL 7
+#define VV_PROF_TEXT 8
+#define VV_PROF_NCLASS 9
+int vv_prof_enable(vv_ctx* ctx, int on);
+/* Synchronises, then fills per class: launches, total ms, algorithmic flops, algorithmic bytes. */
+int vv_prof_collect(vv_ctx* ctx, int64_t* launches, double* ms, double* flops, double* bytes);
+
+/* ---- single-kernel entry points (unit parity tests call these through the ABI) ------------- */
+typedef struct vv_gemm_args {
+    int32_t dtype, out_dtype, mode, act;
+    const void* A; int32_t lda;
+    const void* W; int32_t ldw;
+    void* C; int32_t ldc;
+    int32_t M, N, K;
+    const float *bias, *gate, *cos_q, *sin_q, *cos_k, *sin_k;
+    int32_t n_store, seq_n, rope_dim;
+} vv_gemm_args;
+int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
+
+typedef struct vv_attn_args {
+    int32_t dtype;
+    const void* qkv; int32_t ld_qkv;
+    void* out; int32_t ld_out;
+    int32_t n_seq, seq_n, heads, dim;
+    const int32_t* kv_len;
+} vv_attn_args;
+int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
+
+typedef struct vv_ln_args {
+    int32_t out_dtype;
+    const float* x; int32_t ldx;
+    void* y; int32_t ldy;
+    int32_t R, D;
+    const float *w, *b;
+    int32_t add_one;
+    float eps;
+} vv_ln_args;
+int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
+
+typedef struct vv_posconv_args {
+    int32_t dtype, out_dtype;
+    const void* in; int32_t ld_in;
+    const void* W;            /* bf16: [G][KW][64 co][64 ci]   f32: [G][KW][64 ci][64 co] */
+    const float* bias;
+    void* out; int32_t ld_out;
+    const void* resid; int32_t ld_resid;   /* optional, operand dtype */
+    int32_t n_seq, seq_n, groups, KW, B;
+    const int32_t* seq_len;
+} vv_posconv_args;
+int vv_posconv(vv_ctx* ctx, const vv_posconv_args* args, void* stream);
+
+typedef struct vv_conv_args {
+    const float* in;          /* [B][Cin][T_in]  */
+    const float* W;           /* [Cin_pad8][KW][rows_pad64], rows = co (conv) or co*up + phase (transposed) */
+    const float* bias;        /* [Cout] */
+    float* out;               /* [B][Cout][T_out] */
+    const float* resid;       /* optional, like out */
+    int32_t B, Cin, Cout, T_in, T_out, KW, dil, transposed, up, rows_total, rows_pad, accumulate;
+    float pre_slope, out_scale;
+    const int32_t* len_in;    /* optional per-item valid input length */
+} vv_conv_args;
+int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
+
+int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32,
+                 int B, int C, int T, int KW, float pre_slope, const int32_t* len_in, void* stream);
+int vv_mel(vv_ctx* ctx, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max,
+           void* stream);
+int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,43 @@
+"""Helpers for the -m gpu parity tests: call single kernels through the C ABI."""
+import ctypes as C
+
+import torch
+
+from vietvoice_tts_amd import runtime as rt
+
+DEV = "cuda:0"
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(eng, rc):
+    assert rc == 0, eng.lib.vv_last_error(eng.ctx).decode()
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0):
+    """A [M,K], W [N,K] on device, same dtype (bf16 or f32)."""
+    dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
+    od = dt if out_dtype is None else out_dtype
+    M, K = A.shape
+    N = W.shape[0]
+    if C_io is None:
+        C_io = torch.zeros((M, N), dtype=torch.bfloat16 if od == rt.VV_BF16 else torch.float32, device=DEV)
+    a = rt.vv_gemm_args()
+    a.dtype, a.out_dtype, a.mode, a.act = dt, od, mode, act
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C_io.data_ptr(), C_io.stride(0)
+    a.M, a.N, a.K = M, N, K
+    a.bias = None if bias is None else bias.data_ptr()
+    a.gate = None if gate is None else gate.data_ptr()
+    if ropes is not None:
+        a.cos_q, a.sin_q, a.cos_k, a.sin_k = [t.data_ptr() for t in ropes]
+    a.n_store, a.seq_n, a.rope_dim = n_store, seq_n, rope_dim
+    check(eng, eng.lib.vv_gemm(eng.ctx, C.byref(a), stream()))
+    torch.cuda.synchronize()
+    return C_io

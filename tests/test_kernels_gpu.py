@@ -1,0 +1,363 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against plain-torch fp32 references of the
+same op on the same seeded inputs.  Tolerances: fp32 kernels 2e-4 of the output range (different
+summation order only); bf16 kernels are compared with an fp32 reference fed the SAME bf16-rounded
+operands, 1.5e-2 of the output range (bf16 output rounding + fp32 accumulation order)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 2e-4
+TOL_BF16 = 1.5e-2
+
+
+def _imports():
+    from vietvoice_tts_amd import runtime as rt
+    from tests import gpu_util as gu
+    return rt, gu
+
+
+def _tol(dt):
+    return TOL_BF16 if dt == torch.bfloat16 else TOL_F32
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (128, 128, 64), (1000, 384, 192), (31, 128, 256)])
+def test_gemm_store_bias_act(hip_tiny, dtype, M, N, K):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g) * 0.1
+    for act, fn in ((0, lambda x: x), (1, lambda x: F.gelu(x, approximate="tanh")), (2, F.gelu), (3, F.silu)):
+        ref = fn(A.float() @ W.float().t() + b)
+        got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), act=act)
+        assert gu.rel_err(got, ref) < _tol(dtype), (act, gu.rel_err(got, ref))
+    if dtype == torch.bfloat16:   # bf16 operands, fp32 output
+        got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), out_dtype=rt.VV_F32)
+        assert gu.rel_err(got, A.float() @ W.float().t() + b) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nstore_and_asymmetric(hip_tiny, dtype):
+    """A = I-like with an ASYMMETRIC W catches a transposed C write; n_store masks padded columns."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    M, N, K = 128, 128, 128
+    A = torch.eye(M, K).to(dtype)
+    W = (torch.arange(N).float()[:, None] * 0.01 + torch.arange(K).float()[None, :] * 0.5).to(dtype)
+    C0 = torch.full((M, N), 7.0, dtype=torch.float32, device=gu.DEV)
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), out_dtype=rt.VV_F32, C_io=C0, n_store=100)
+    ref = A.float() @ W.float().t()
+    assert gu.rel_err(got[:, :100], ref[:, :100]) < 1e-6
+    assert torch.all(got[:, 100:].cpu() == 7.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_gate_residual(hip_tiny, dtype):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    M, N, K = 260, 256, 128
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b, gate = torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g)
+    x0 = torch.randn(M, N, generator=g)
+    ref = x0 + gate * (A.float() @ W.float().t() + b)
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, gate=gate.to(gu.DEV),
+                  C_io=x0.clone().to(gu.DEV))
+    assert gu.rel_err(got, ref) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
+    ref1 = x0 + (A.float() @ W.float().t() + b)
+    got1 = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, C_io=x0.clone().to(gu.DEV))
+    assert gu.rel_err(got1, ref1) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_qkv_rope(hip_tiny, dtype, tiny_setup):
+    rt, gu = _imports()
+    from oracle.vv_oracle import Oracle
+    spec, _, orc = tiny_setup
+    eng = hip_tiny["f32"]
+    D, seq_n, n_seq = 128, 70, 3
+    M = seq_n * n_seq
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, D, generator=g).to(dtype)
+    W = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(dtype)
+    b = torch.randn(3 * D, generator=g) * 0.1
+    ropes = orc.rope_tables(seq_n)
+    y = A.float() @ W.float().t() + b
+    q, k, v = y.split(D, dim=-1)
+    pos_tab = [t.repeat(n_seq, 1) for t in ropes]
+    qr = Oracle.rope_apply(q.reshape(M, 2, 64), pos_tab[0], pos_tab[1]).reshape(M, D)
+    kr = Oracle.rope_apply(k.reshape(M, 2, 64), pos_tab[2], pos_tab[3]).reshape(M, D)
+    ref = torch.cat([qr, kr, v], dim=-1)
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=[t.contiguous().to(gu.DEV) for t in ropes],
+                  seq_n=seq_n, rope_dim=D)
+    assert gu.rel_err(got, ref) < _tol(dtype)
+
+
+def test_gemm_rejects_bad_shapes(hip_tiny):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    A = torch.zeros(8, 64, device=gu.DEV)
+    W = torch.zeros(100, 64, device=gu.DEV)     # N not a multiple of 128
+    a = rt.vv_gemm_args()
+    a.dtype = a.out_dtype = rt.VV_F32
+    out = torch.zeros(8, 100, device=gu.DEV)
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = A.data_ptr(), 64, W.data_ptr(), 64, out.data_ptr(), 100, 8, 100, 64
+    rc = eng.lib.vv_gemm(eng.ctx, C.byref(a), gu.stream())
+    assert rc != 0 and b"multiple of 128" in eng.lib.vv_last_error(eng.ctx)
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seq_n,lens", [(200, [200, 137, 64]), (64, [64, 1, 33]), (333, [333, 300, 129])])
+def test_attention(hip_tiny, dtype, seq_n, lens):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    heads, D, n_seq = 2, 128, len(lens)
+    g = torch.Generator().manual_seed(seq_n)
+    qkv = torch.randn(n_seq * seq_n, 3 * D, generator=g)
+    qkv[:, :D] *= 0.35          # q carries the softmax scale in the real pipeline
+    qkv = qkv.to(dtype)
+    out = torch.zeros(n_seq * seq_n, D, dtype=dtype, device=gu.DEV)
+    kv = torch.tensor(lens, dtype=torch.int32, device=gu.DEV)
+    a = rt.vv_attn_args()
+    a.dtype = rt.VV_BF16 if dtype == torch.bfloat16 else rt.VV_F32
+    dq = qkv.to(gu.DEV)
+    a.qkv, a.ld_qkv, a.out, a.ld_out = dq.data_ptr(), 3 * D, out.data_ptr(), D
+    a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len = n_seq, seq_n, heads, D, kv.data_ptr()
+    gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    f = qkv.float().reshape(n_seq, seq_n, 3, heads, 64)
+    for s, L in enumerate(lens):
+        q, k, v = f[s, :, 0], f[s, :L, 1], f[s, :L, 2]
+        sc = torch.einsum("qhd,khd->hqk", q, k)
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), v).reshape(seq_n, D)
+        got = out[s * seq_n:(s + 1) * seq_n]
+        assert gu.rel_err(got[:L], ref[:L]) < _tol(dtype), (s, gu.rel_err(got[:L], ref[:L]))
+
+
+def test_attention_spiked_max(hip_tiny):
+    """Online-softmax rescale branch: a key late in the sequence dominates one query row."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    seq_n, D = 256, 128
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(seq_n, 3 * D, generator=g) * 0.3
+    qkv[5, :64] = 3.0
+    qkv[200, D:D + 64] = 3.0      # q5 . k200 = 576 >> everything else
+    for dtype in (torch.float32, torch.bfloat16):
+        x = qkv.to(dtype)
+        out = torch.zeros(seq_n, D, dtype=dtype, device=gu.DEV)
+        a = rt.vv_attn_args()
+        a.dtype = rt.VV_BF16 if dtype == torch.bfloat16 else rt.VV_F32
+        dq = x.to(gu.DEV)
+        a.qkv, a.ld_qkv, a.out, a.ld_out, a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len = dq.data_ptr(), 3 * D, out.data_ptr(), D, 1, seq_n, 2, D, None
+        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        f = x.float().reshape(seq_n, 3, 2, 64)
+        sc = torch.einsum("qhd,khd->hqk", f[:, 0], f[:, 1])
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), f[:, 2]).reshape(seq_n, D)
+        assert gu.rel_err(out, ref) < _tol(dtype)
+
+
+# ------------------------------------------------------------------------------------ LayerNorm / AdaLN
+@pytest.mark.parametrize("D", [128, 512, 1024])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_modulate(hip_tiny, D, out_dtype):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    R = 37
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(R, D, generator=g) * 2 + 0.5
+    sc, sh = torch.randn(D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    y = torch.zeros(R, D, dtype=out_dtype, device=gu.DEV)
+    dx, dsc, dsh = x.to(gu.DEV), sc.to(gu.DEV), sh.to(gu.DEV)
+    for add_one in (1, 0):
+        a = rt.vv_ln_args()
+        a.out_dtype = rt.VV_BF16 if out_dtype == torch.bfloat16 else rt.VV_F32
+        a.x, a.ldx, a.y, a.ldy, a.R, a.D, a.w, a.b, a.add_one, a.eps = dx.data_ptr(), D, y.data_ptr(), D, R, D, dsc.data_ptr(), dsh.data_ptr(), add_one, 1e-6
+        gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        ref = F.layer_norm(x, (D,), eps=1e-6) * (sc + add_one) + sh
+        assert gu.rel_err(y, ref) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
+
+
+# ------------------------------------------------------------------------------------ conv position embedding
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_posconv(hip_tiny, dtype):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    G, KW, seq_n, lens = 2, 31, 150, [150, 97]
+    D = G * 64
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(len(lens) * seq_n, D, generator=g).to(dtype)
+    w = (torch.randn(D, 64, KW, generator=g) / math.sqrt(64 * KW)).to(dtype)
+    b = torch.randn(D, generator=g) * 0.1
+    res = torch.randn(len(lens) * seq_n, D, generator=g).to(dtype)
+    if dtype == torch.bfloat16:
+        wp = w.reshape(G, 64, 64, KW).permute(0, 3, 1, 2).contiguous()
+    else:
+        wp = w.reshape(G, 64, 64, KW).permute(0, 3, 2, 1).contiguous()
+    out = torch.zeros(len(lens) * seq_n, D, dtype=torch.float32, device=gu.DEV)
+    dx, dw, db, dr = x.to(gu.DEV), wp.to(gu.DEV), b.to(gu.DEV), res.to(gu.DEV)
+    sl = torch.tensor(lens, dtype=torch.int32, device=gu.DEV)
+    a = rt.vv_posconv_args()
+    a.dtype = rt.VV_BF16 if dtype == torch.bfloat16 else rt.VV_F32
+    a.out_dtype = rt.VV_F32
+    a.in_, a.ld_in, a.W, a.bias, a.out, a.ld_out, a.resid, a.ld_resid = dx.data_ptr(), D, dw.data_ptr(), db.data_ptr(), out.data_ptr(), D, dr.data_ptr(), D
+    a.n_seq, a.seq_n, a.groups, a.KW, a.B, a.seq_len = len(lens), seq_n, G, KW, len(lens), sl.data_ptr()
+    gu.check(eng, eng.lib.vv_posconv(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    for s, L in enumerate(lens):
+        xs = x.float()[s * seq_n: s * seq_n + L]
+        ref = F.mish(F.conv1d(xs.t().unsqueeze(0), w.float(), b, padding=KW // 2, groups=G)).squeeze(0).t() + res.float()[s * seq_n: s * seq_n + L]
+        got = out[s * seq_n: s * seq_n + L]
+        assert gu.rel_err(got, ref) < (5e-3 if dtype == torch.bfloat16 else TOL_F32), gu.rel_err(got, ref)
+
+
+# ------------------------------------------------------------------------------------ vocoder convs
+def _pack_conv(w):        # torch [Cout][Cin][KW] -> [Cin_pad8][KW][Cout_pad64]
+    cout, cin, kw = w.shape
+    t = torch.zeros(((cin + 7) // 8 * 8, kw, (cout + 63) // 64 * 64))
+    t[:cin, :, :cout] = w.permute(1, 2, 0)
+    return t
+
+
+def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pre_slope=1.0, scale=1.0, accumulate=0, out0=None, lens=None):
+    B, cin, T_in = x.shape
+    out = out0.clone().to(gu.DEV) if out0 is not None else torch.zeros(B, cout, T_out, device=gu.DEV)
+    dx, dw, db = x.to(gu.DEV), wp.to(gu.DEV), bias.to(gu.DEV)
+    dr = resid.to(gu.DEV) if resid is not None else None
+    dl = torch.tensor(lens, dtype=torch.int32, device=gu.DEV) if lens is not None else None
+    a = rt.vv_conv_args()
+    a.in_, a.W, a.bias, a.out = dx.data_ptr(), dw.data_ptr(), db.data_ptr(), out.data_ptr()
+    a.resid = dr.data_ptr() if dr is not None else None
+    a.B, a.Cin, a.Cout, a.T_in, a.T_out, a.KW, a.dil = B, cin, cout, T_in, T_out, KW, dil
+    a.transposed, a.up = (1 if up else 0), up
+    a.rows_total = cout * up if up else cout
+    a.rows_pad = (a.rows_total + 63) // 64 * 64
+    a.accumulate, a.pre_slope, a.out_scale = accumulate, pre_slope, scale
+    a.len_in = dl.data_ptr() if dl is not None else None
+    gu.check(eng, eng.lib.vv_conv1d(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("KW,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5), (7, 1)])
+@pytest.mark.parametrize("cin,cout,T", [(20, 24, 300), (64, 64, 517), (100, 128, 40)])
+def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(KW * 100 + dil + cin)
+    B = 2
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin, KW, generator=g) / math.sqrt(cin * KW)
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, T, generator=g)
+    prev = torch.randn(B, cout, T, generator=g)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=dil, padding=dil * (KW - 1) // 2)
+    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, pre_slope=0.1)
+    assert gu.rel_err(got, ref) < TOL_F32
+    ref2 = prev + (ref + res) / 3.0
+    got2 = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, resid=res, pre_slope=0.1, scale=1.0 / 3.0, accumulate=1, out0=prev)
+    assert gu.rel_err(got2, ref2) < TOL_F32
+
+
+def test_conv1d_length_mask(hip_tiny):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 300, generator=g)
+    w = torch.randn(16, 16, 7, generator=g) / 10
+    b = torch.zeros(16)
+    lens = [300, 123]
+    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, 16, 300, 7, 3, 0, lens=lens)
+    for i, L in enumerate(lens):
+        ref = F.conv1d(x[i:i + 1, :, :L], w, b, dilation=3, padding=9)
+        assert gu.rel_err(got[i:i + 1, :, :L], ref) < TOL_F32
+
+
+@pytest.mark.parametrize("u,cin,cout,T", [(8, 32, 16, 70), (2, 16, 8, 300), (8, 64, 32, 257), (2, 128, 64, 40)])
+def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(u * 31 + cin)
+    B = 2
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cin, cout, 2 * u, generator=g) / math.sqrt(2 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=u // 2)
+    rows = cout * u
+    wp = torch.zeros(((cin + 7) // 8 * 8, 2, (rows + 63) // 64 * 64))
+    wp[:cin, :, :rows] = w.reshape(cin, cout, 2, u).permute(0, 2, 1, 3).reshape(cin, 2, rows)
+    got = _run_conv(eng, rt, gu, x, wp, b, cout, T * u, 2, 1, u, pre_slope=0.1)
+    assert ref.shape == got.shape
+    assert gu.rel_err(got, ref) < TOL_F32
+
+
+def test_conv_post_pcm(hip_tiny):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(23)
+    B, Cc, T = 2, 32, 3000
+    x = torch.randn(B, Cc, T, generator=g)
+    w = torch.randn(1, Cc, 7, generator=g) / math.sqrt(Cc * 7) * 0.7
+    bias = 0.05
+    ref = torch.tanh(F.conv1d(F.leaky_relu(x, 0.01), w, torch.tensor([bias]), padding=3)).reshape(B, T)
+    pcm = torch.zeros(B, T, dtype=torch.int16, device=gu.DEV)
+    wave = torch.zeros(B, T, device=gu.DEV)
+    dx, dw = x.to(gu.DEV), w.reshape(Cc, 7).contiguous().to(gu.DEV)
+    gu.check(eng, eng.lib.vv_conv_post(eng.ctx, dx.data_ptr(), dw.data_ptr(), bias, pcm.data_ptr(), T, wave.data_ptr(), B, Cc, T, 7, 0.01, None, gu.stream()))
+    torch.cuda.synchronize()
+    assert gu.rel_err(wave, ref) < TOL_F32
+    ref_pcm = torch.clamp(ref * 32767.0, -32768.0, 32767.0).to(torch.int16)
+    assert int((pcm.cpu().int() - ref_pcm.int()).abs().max()) <= 1      # +-1 LSB
+
+
+# ------------------------------------------------------------------------------------ mel front end
+def test_mel_frontend(hip_tiny, tiny_setup):
+    rt, gu = _imports()
+    spec, _, orc = tiny_setup
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(31)
+    lens = [256 * 20, 256 * 13 + 77]
+    S = max(lens)
+    audio = (torch.randn(2, S, generator=g) * 4000).clamp(-30000, 30000).to(torch.int16)
+    t = torch.arange(S) / 24000.0
+    audio[0] = (torch.sin(2 * math.pi * 440 * t) * 12000 + torch.sin(2 * math.pi * 3000 * t) * 3000).to(torch.int16)
+    F_max = S // 256 + 1
+    mel = torch.zeros(2, F_max, spec.n_mel, device=gu.DEV)
+    da = audio.to(gu.DEV)
+    dl = torch.tensor(lens, dtype=torch.int32, device=gu.DEV)
+    gu.check(eng, eng.lib.vv_mel(eng.ctx, da.data_ptr(), S, dl.data_ptr(), mel.data_ptr(), 2, F_max, gu.stream()))
+    torch.cuda.synchronize()
+    for i, L in enumerate(lens):
+        ref = orc.mel(audio[i, :L])
+        got = mel[i, : ref.shape[0]].cpu()
+        assert ref.shape[0] == L // 256 + 1
+        assert float((got - ref).abs().max()) < 2e-3, float((got - ref).abs().max())     # log domain, abs
+        if i == 0:   # known answer: a 440 Hz tone peaks in the mel bin whose centre is nearest 440 Hz
+            peak = int(ref[10].argmax())
+            assert int(got[10].argmax()) == peak
+
+
+def test_cfg_euler(hip_tiny):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(41)
+    BN, M, ldp = 77, 100, 128
+    x = torch.randn(BN, M, generator=g)
+    pred = torch.randn(2 * BN, ldp, generator=g)
+    ref = x + 0.03 * (pred[:BN, :M] + (pred[:BN, :M] - pred[BN:, :M]) * 2.0)
+    dx, dp = x.clone().to(gu.DEV), pred.to(gu.DEV)
+    gu.check(eng, eng.lib.vv_cfg_euler(eng.ctx, dx.data_ptr(), dp.data_ptr(), ldp, BN, M, 2.0, 0.03, gu.stream()))
+    torch.cuda.synchronize()
+    assert gu.rel_err(dx, ref) < 1e-6

@@ -1,0 +1,590 @@
+// C ABI + native stage drivers: context, named weight binding, workspace arena, the preprocess /
+// transformer-steps / decode launch sequences, and HIP-event profiling per kernel class.
+// No torch types, no exceptions across the ABI, no device allocation inside the step loop.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "vv_kernels.h"
+
+#define VV_VERSION_STR "vvtts-hip 0.1 (gfx950)"
+
+namespace {
+std::string g_create_error;
+
+struct Bound { const void* p; uint64_t bytes; };
+
+struct ProfRec { hipEvent_t a, b; int cls; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pad_to(int v, int a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+struct vv_ctx {
+    int device = 0;
+    vv_model_cfg cfg{};
+    int dt = VV_DTYPE_BF16;             // acoustic operand dtype
+    std::string err;
+    std::map<std::string, Bound> w;
+    bool finalized = false;
+    float post_bias = 0.f;
+    // time grid tables
+    int n_steps = 0;
+    std::vector<float> dt_host;
+    float* modtab = nullptr;            // [depth][n_steps][6D]
+    float* fintab = nullptr;            // [n_steps][2D]
+    // workspace arena
+    char* ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    int* d_mult = nullptr;              // decode length multipliers
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    int64_t p_launch[VV_PROF_NCLASS]{};
+    double p_flops[VV_PROF_NCLASS]{}, p_bytes[VV_PROF_NCLASS]{}, p_ms[VV_PROF_NCLASS]{};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    const void* W(const std::string& n) const {
+        auto it = w.find(n);
+        return it == w.end() ? nullptr : it->second.p;
+    }
+    const float* Wf(const std::string& n) const { return (const float*)W(n); }
+    int esz() const { return dt == VV_DTYPE_BF16 ? 2 : 4; }
+    int bk() const { return dt == VV_DTYPE_BF16 ? 64 : 32; }
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) return (ctx)->fail(-5, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+#define KCHK(ctx, call)                                              \
+    do {                                                             \
+        const char* m__ = "";                                        \
+        int r__ = (call);                                            \
+        if (r__ != 0) return (ctx)->fail(r__, "%s", m__);            \
+    } while (0)
+
+struct Prof {
+    vv_ctx* c; int idx = -1; hipStream_t st;
+    Prof(vv_ctx* c_, int cls, double flops, double bytes, hipStream_t st_) : c(c_), st(st_) {
+        if (!c->prof) return;
+        ProfRec r; r.cls = cls;
+        auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else hipEventCreate(&e); return e; };
+        r.a = get(); r.b = get();
+        hipEventRecord(r.a, st);
+        c->recs.push_back(r); idx = (int)c->recs.size() - 1;
+        c->p_launch[cls]++; c->p_flops[cls] += flops; c->p_bytes[cls] += bytes;
+    }
+    ~Prof() { if (idx >= 0) hipEventRecord(c->recs[idx].b, st); }
+};
+
+int ensure_ws(vv_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_cap) { c->ws_off = 0; return 0; }
+    if (c->ws) { hipDeviceSynchronize(); hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
+    const size_t want = align_up(bytes + bytes / 16, 1 << 20);
+    hipError_t e = hipMalloc((void**)&c->ws, want);
+    if (e != hipSuccess) return c->fail(-12, "workspace hipMalloc(%zu MiB): %s", want >> 20, hipGetErrorString(e));
+    c->ws_cap = want; c->ws_off = 0;
+    return 0;
+}
+template <typename T> T* carve(vv_ctx* c, size_t n) {
+    c->ws_off = align_up(c->ws_off, 256);
+    T* p = (T*)(c->ws + c->ws_off);
+    c->ws_off += n * sizeof(T);
+    return p;
+}
+struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + bytes; } };
+
+// ---- GEMM helper over bound weights -------------------------------------------------------
+int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
+         void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
+         const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1) {
+    vv_gemm_args g{};
+    g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
+    g.A = A; g.lda = lda; g.W = c->W(wname); g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
+    if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; }
+    if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
+    const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
+    const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
+    Prof p(c, VV_PROF_GEMM, fl, (double)M * K * esz + (double)N * K * esz + (double)M * N * osz * (mode == VV_EPI_GATE_RES ? 2 : 1), st);
+    const char* m = "";
+    int r = vvk_gemm(&g, st, &m);
+    if (r) return c->fail(r, "%s (weight %s, M=%d N=%d K=%d)", m, wname, M, N, K);
+    return 0;
+}
+
+std::string blk(int i, const char* s) { return "blocks." + std::to_string(i) + s; }
+
+}  // namespace
+
+// =====================================================================================  ABI
+extern "C" {
+
+const char* vv_version(void) { return VV_VERSION_STR; }
+
+const char* vv_last_error(const vv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vv_create(vv_ctx** out, int device, const vv_model_cfg* cfg, int acoustic_dtype) {
+    if (!out || !cfg) { g_create_error = "vv_create: null argument"; return -22; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = "vv_create: no HIP device visible (the HIP path has no CPU fallback)"; return -19; }
+    if (device < 0 || device >= n) { g_create_error = "vv_create: device index out of range"; return -22; }
+    if (acoustic_dtype != VV_DTYPE_F32 && acoustic_dtype != VV_DTYPE_BF16) { g_create_error = "vv_create: dtype must be f32 or bf16"; return -22; }
+    if (cfg->head_dim != 64 || cfg->heads * 64 != cfg->dim) { g_create_error = "vv_create: head_dim must be 64"; return -22; }
+    if (cfg->dim % 128 || cfg->text_dim % 128 || cfg->dim / cfg->pos_conv_groups != 64 || cfg->n_mel % 4 || cfg->dim > 1024 ||
+        cfg->text_dim > 1024) {
+        g_create_error = "vv_create: dim/text_dim must be multiples of 128 (<=1024), 64 channels per pos-conv group"; return -22;
+    }
+    if (cfg->voc_n_up < 1 || cfg->voc_n_up > VV_MAX_UP || cfg->voc_n_res > VV_MAX_RES || cfg->voc_n_dil > VV_MAX_RES) {
+        g_create_error = "vv_create: vocoder topology out of range"; return -22;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return -5; }
+    vv_ctx* c = new vv_ctx();
+    c->device = device; c->cfg = *cfg; c->dt = acoustic_dtype;
+    *out = c;
+    return 0;
+}
+
+void vv_destroy(vv_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->ws) hipFree(c->ws);
+    if (c->modtab) hipFree(c->modtab);
+    if (c->fintab) hipFree(c->fintab);
+    if (c->d_mult) hipFree(c->d_mult);
+    for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto e : c->pool) hipEventDestroy(e);
+    delete c;
+}
+
+int vv_bind_weight(vv_ctx* c, const char* name, const void* p, uint64_t bytes) {
+    if (!c || !name || !p) return c ? c->fail(-22, "vv_bind_weight: null argument") : -22;
+    if ((uintptr_t)p % 16) return c->fail(-22, "vv_bind_weight(%s): pointer must be 16-byte aligned", name);
+    c->w[name] = Bound{p, bytes};
+    c->finalized = false;
+    return 0;
+}
+
+int vv_finalize_weights(vv_ctx* c) {
+    if (!c) return -22;
+    const vv_model_cfg& g = c->cfg;
+    const int D = g.dim, Dt = g.text_dim, FF = g.dim * g.ff_mult, es = c->esz();
+    const int KP = pad_to(2 * g.n_mel + Dt, 64), MP = pad_to(g.n_mel, 128);
+    std::string missing;
+    auto need = [&](const std::string& n, uint64_t bytes) {
+        auto it = c->w.find(n);
+        if (it == c->w.end()) { missing += n + " "; return; }
+        if (it->second.bytes < bytes) missing += n + "(short:" + std::to_string(it->second.bytes) + "<" + std::to_string(bytes) + ") ";
+    };
+    need("const.window", 4ull * g.n_fft); need("const.tw_cos", 4ull * g.n_fft); need("const.tw_sin", 4ull * g.n_fft);
+    need("const.mel_fb", 4ull * (g.n_fft / 2 + 1) * g.n_mel);
+    need("const.text_pos", 4ull * g.max_pos * Dt);
+    need("text.embed.weight", 4ull * g.vocab_rows * Dt);
+    for (int i = 0; i < g.text_layers; ++i) {
+        const std::string p = "text.blocks." + std::to_string(i);
+        need(p + ".dwconv.weight", 4ull * Dt * g.text_conv_k); need(p + ".dwconv.bias", 4ull * Dt);
+        need(p + ".norm.weight", 4ull * Dt); need(p + ".norm.bias", 4ull * Dt);
+        need(p + ".pwconv1.weight", (uint64_t)es * Dt * g.text_ff_mult * Dt); need(p + ".pwconv1.bias", 4ull * Dt * g.text_ff_mult);
+        need(p + ".grn.gamma", 4ull * Dt * g.text_ff_mult); need(p + ".grn.beta", 4ull * Dt * g.text_ff_mult);
+        need(p + ".pwconv2.weight", (uint64_t)es * Dt * g.text_ff_mult * Dt); need(p + ".pwconv2.bias", 4ull * Dt);
+    }
+    need("input.proj.weight", (uint64_t)es * D * KP); need("input.proj.bias", 4ull * D);
+    for (int j = 1; j <= 2; ++j) {
+        need("input.pos_conv" + std::to_string(j) + ".weight", (uint64_t)es * D * 64 * g.pos_conv_k);
+        need("input.pos_conv" + std::to_string(j) + ".bias", 4ull * D);
+    }
+    need("time.mlp1.weight", 4ull * D * g.time_freq_dim); need("time.mlp1.bias", 4ull * D);
+    need("time.mlp2.weight", 4ull * D * D); need("time.mlp2.bias", 4ull * D);
+    for (int i = 0; i < g.depth; ++i) {
+        need(blk(i, ".adaln.weight"), 4ull * 6 * D * D); need(blk(i, ".adaln.bias"), 4ull * 6 * D);
+        need(blk(i, ".attn.qkv.weight"), (uint64_t)es * 3 * D * D); need(blk(i, ".attn.qkv.bias"), 4ull * 3 * D);
+        need(blk(i, ".attn.out.weight"), (uint64_t)es * D * D); need(blk(i, ".attn.out.bias"), 4ull * D);
+        need(blk(i, ".ff1.weight"), (uint64_t)es * FF * D); need(blk(i, ".ff1.bias"), 4ull * FF);
+        need(blk(i, ".ff2.weight"), (uint64_t)es * D * FF); need(blk(i, ".ff2.bias"), 4ull * D);
+    }
+    need("final.adaln.weight", 4ull * 2 * D * D); need("final.adaln.bias", 4ull * 2 * D);
+    need("final.proj.weight", (uint64_t)es * MP * D); need("final.proj.bias", 4ull * MP);
+    int ch = g.voc_pre_ch;
+    need("voc.pre.weight", 4ull * pad_to(g.n_mel, 8) * g.voc_pre_k * pad_to(ch, 64)); need("voc.pre.bias", 4ull * ch);
+    for (int s = 0; s < g.voc_n_up; ++s) {
+        const int cin = ch, cout = ch / 2, u = g.voc_up_rates[s];
+        const std::string p = "voc.up." + std::to_string(s);
+        need(p + ".weight", 4ull * pad_to(cin, 8) * 2 * pad_to(cout * u, 64)); need(p + ".bias", 4ull * cout);
+        for (int a = 0; a < g.voc_n_res; ++a)
+            for (int b = 0; b < g.voc_n_dil; ++b)
+                for (int k = 1; k <= 2; ++k) {
+                    const std::string q = "voc.res." + std::to_string(s) + "." + std::to_string(a) + "." + std::to_string(b) + ".conv" + std::to_string(k);
+                    need(q + ".weight", 4ull * pad_to(cout, 8) * g.voc_res_kernels[a] * pad_to(cout, 64)); need(q + ".bias", 4ull * cout);
+                }
+        ch = cout;
+    }
+    need("voc.post.weight", 4ull * ch * g.voc_post_k); need("voc.post.bias", 4);
+    if (!missing.empty()) return c->fail(-2, "missing or short weights: %s", missing.c_str());
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(&c->post_bias, c->W("voc.post.bias"), 4, hipMemcpyDeviceToHost));
+    // decode length multipliers: level 0 = frames, level s+1 = after upsample s
+    std::vector<int> mult(g.voc_n_up + 1, 1);
+    for (int s = 0; s < g.voc_n_up; ++s) mult[s + 1] = mult[s] * g.voc_up_rates[s];
+    if (!c->d_mult) HIPCHK(c, hipMalloc((void**)&c->d_mult, sizeof(int) * (VV_MAX_UP + 1)));
+    HIPCHK(c, hipMemcpy(c->d_mult, mult.data(), sizeof(int) * mult.size(), hipMemcpyHostToDevice));
+    c->finalized = true;
+    return 0;
+}
+
+int vv_set_time_grid(vv_ctx* c, const float* sinus_host, const float* dt_host, int n_steps, void* stream) {
+    if (!c) return -22;
+    if (!c->finalized) return c->fail(-1, "vv_set_time_grid: weights not finalized");
+    if (n_steps < 1 || n_steps > 512 || !sinus_host || !dt_host) return c->fail(-22, "vv_set_time_grid: bad arguments");
+    hipSetDevice(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = c->cfg.dim, S = n_steps, TF = c->cfg.time_freq_dim, L = c->cfg.depth;
+    if (TF % 32) return c->fail(-22, "time_freq_dim must be a multiple of 32");
+    if (c->modtab) { hipDeviceSynchronize(); hipFree(c->modtab); hipFree(c->fintab); c->modtab = c->fintab = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->modtab, sizeof(float) * (size_t)L * S * 6 * D));
+    HIPCHK(c, hipMalloc((void**)&c->fintab, sizeof(float) * (size_t)S * 2 * D));
+    Need nd; nd.add(4ull * S * TF); nd.add(4ull * S * D); nd.add(4ull * S * D);
+    if (int r = ensure_ws(c, nd.b)) return r;
+    float* sin_d = carve<float>(c, (size_t)S * TF);
+    float* t1 = carve<float>(c, (size_t)S * D);
+    float* t2 = carve<float>(c, (size_t)S * D);
+    HIPCHK(c, hipMemcpyAsync(sin_d, sinus_host, 4ull * S * TF, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));     // host buffer may be pageable; keep its lifetime simple
+    if (int r = gemm(c, VV_DTYPE_F32, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_SILU_, sin_d, TF, "time.mlp1.weight", TF, "time.mlp1.bias", t1, D, S, D, TF, st)) return r;
+    if (int r = gemm(c, VV_DTYPE_F32, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_SILU_, t1, D, "time.mlp2.weight", D, "time.mlp2.bias", t2, D, S, D, D, st)) return r;
+    // t2 = SiLU(t_emb): every AdaLN consumes the embedding through SiLU only
+    for (int l = 0; l < L; ++l) {
+        const std::string wn = blk(l, ".adaln.weight"), bn = blk(l, ".adaln.bias");
+        if (int r = gemm(c, VV_DTYPE_F32, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, t2, D, wn.c_str(), D, bn.c_str(),
+                         c->modtab + (size_t)l * S * 6 * D, 6 * D, S, 6 * D, D, st)) return r;
+    }
+    if (int r = gemm(c, VV_DTYPE_F32, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, t2, D, "final.adaln.weight", D, "final.adaln.bias", c->fintab, 2 * D, S, 2 * D, D, st)) return r;
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->n_steps = S;
+    c->dt_host.assign(dt_host, dt_host + S);
+    return 0;
+}
+
+// --------------------------------------------------------------------------------- preprocess
+int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len, const int32_t* audio_len,
+                  const int32_t* text_ids, int ld_text, const int32_t* text_len, const int32_t* seq_len, float* cat,
+                  float* cat_drop, int32_t* ref_len, void* stream) {
+    if (!c) return -22;
+    if (!c->finalized) return c->fail(-1, "vv_preprocess: weights not finalized");
+    if (B < 1 || N < 1 || !audio || !audio_len || !text_ids || !text_len || !seq_len || !cat || !cat_drop || !ref_len)
+        return c->fail(-22, "vv_preprocess: bad arguments");
+    const vv_model_cfg& g = c->cfg;
+    if (N > g.max_pos) return c->fail(-22, "vv_preprocess: N=%d exceeds the position tables (%d)", N, g.max_pos);
+    if (max_audio_len < g.n_fft || max_audio_len > ld_audio) return c->fail(-22, "vv_preprocess: reference clips must hold >= n_fft samples and fit ld_audio");
+    hipSetDevice(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int Dt = g.text_dim, C2 = Dt * g.text_ff_mult, M = g.n_mel, es = c->esz();
+    const int F_max = max_audio_len / g.hop_length + 1;
+    const size_t R2 = (size_t)2 * B * N;
+    Need nd;
+    nd.add(4ull * B * F_max * M); nd.add(4ull * R2 * Dt); nd.add(4ull * R2 * Dt); nd.add((size_t)es * R2 * Dt);
+    nd.add((size_t)es * R2 * C2); nd.add(4ull * 2 * B * C2);
+    if (int r = ensure_ws(c, nd.b)) return r;
+    float* mel = carve<float>(c, (size_t)B * F_max * M);
+    float* tx = carve<float>(c, R2 * Dt);
+    float* ty = carve<float>(c, R2 * Dt);
+    char* th = carve<char>(c, (size_t)es * R2 * Dt);
+    char* tm = carve<char>(c, (size_t)es * R2 * C2);
+    float* sumsq = carve<float>(c, (size_t)2 * B * C2);
+
+    KCHK(c, vvk_ref_len(audio_len, ref_len, B, g.hop_length, st, &m__));
+    {
+        Prof p(c, VV_PROF_MEL, 4.0 * B * F_max * (double)g.n_fft * (g.n_fft / 2 + 1), 2.0 * B * max_audio_len + 4.0 * B * F_max * M, st);
+        KCHK(c, vvk_mel(audio, ld_audio, audio_len, c->Wf("const.window"), c->Wf("const.tw_cos"), c->Wf("const.tw_sin"),
+                        c->Wf("const.mel_fb"), mel, B, F_max, g.n_fft, g.hop_length, M, st, &m__));
+    }
+    {
+        Prof p(c, VV_PROF_TEXT, 0, 8.0 * R2 * Dt, st);
+        KCHK(c, vvk_text_embed(text_ids, ld_text, text_len, c->Wf("text.embed.weight"), c->Wf("const.text_pos"), tx, B, N, Dt, g.vocab_rows, st, &m__));
+    }
+    for (int i = 0; i < g.text_layers; ++i) {
+        const std::string p = "text.blocks." + std::to_string(i);
+        {
+            Prof pr(c, VV_PROF_TEXT, 2.0 * R2 * Dt * g.text_conv_k, 8.0 * R2 * Dt, st);
+            KCHK(c, vvk_dwconv(tx, ty, c->Wf(p + ".dwconv.weight"), c->Wf(p + ".dwconv.bias"), seq_len, B, 2 * B, N, Dt, g.text_conv_k, st, &m__));
+        }
+        {
+            vv_ln_args a{}; a.out_dtype = c->dt; a.x = ty; a.ldx = Dt; a.y = th; a.ldy = Dt; a.R = (int)R2; a.D = Dt;
+            a.w = c->Wf(p + ".norm.weight"); a.b = c->Wf(p + ".norm.bias"); a.add_one = 0; a.eps = 1e-6f;
+            Prof pr(c, VV_PROF_NORM, 0, (4.0 + es) * R2 * Dt, st);
+            KCHK(c, vvk_ln_mod(&a, st, &m__));
+        }
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_ERF_, th, Dt, (p + ".pwconv1.weight").c_str(), Dt, (p + ".pwconv1.bias").c_str(), tm, C2, (int)R2, C2, Dt, st)) return r;
+        {
+            Prof pr(c, VV_PROF_TEXT, 0, 3.0 * es * R2 * C2, st);
+            KCHK(c, vvk_grn(c->dt, tm, sumsq, c->Wf(p + ".grn.gamma"), c->Wf(p + ".grn.beta"), seq_len, B, 2 * B, N, C2, st, &m__));
+        }
+        if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_GATE_RES, VV_ACT_NONE_, tm, C2, (p + ".pwconv2.weight").c_str(), C2, (p + ".pwconv2.bias").c_str(), tx, Dt, (int)R2, Dt, C2, st)) return r;
+    }
+    {
+        Prof p(c, VV_PROF_ELEMWISE, 0, 12.0 * B * N * (M + Dt), st);
+        KCHK(c, vvk_build_cat(mel, F_max, ref_len, tx, cat, cat_drop, B, N, M, Dt, st, &m__));
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------- transformer steps
+int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float* x, const float* cat, const float* cat_drop,
+                         const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
+                         int step0, int n_steps, void* stream) {
+    if (!c) return -22;
+    if (!c->finalized || !c->modtab) return c->fail(-1, "vv_transformer_steps: weights/time grid not ready");
+    if (B < 1 || N < 1 || !seq_len || !x || !cat || !cat_drop || !rope_cos_q || !rope_sin_q || !rope_cos_k || !rope_sin_k)
+        return c->fail(-22, "vv_transformer_steps: bad arguments");
+    if (step0 < 0 || n_steps < 0 || step0 + n_steps > c->n_steps) return c->fail(-22, "vv_transformer_steps: steps [%d,%d) outside the time grid (%d)", step0, step0 + n_steps, c->n_steps);
+    const vv_model_cfg& g = c->cfg;
+    hipSetDevice(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = g.dim, FF = D * g.ff_mult, M = g.n_mel, CD = M + g.text_dim, es = c->esz();
+    const int KP = pad_to(M + CD, 64), MP = pad_to(M, 128);
+    const size_t R = (size_t)2 * B * N;
+    if (R > (size_t)1 << 30) return c->fail(-22, "batch too large");
+    const int S = c->n_steps;
+    Need nd;
+    nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
+    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B);
+    if (int r = ensure_ws(c, nd.b)) return r;
+    char* xcat = carve<char>(c, es * R * KP);
+    char* h = carve<char>(c, es * R * D);
+    char* h2 = carve<char>(c, es * R * D);
+    float* xres = carve<float>(c, R * D);
+    char* qkv = carve<char>(c, es * R * 3 * D);
+    char* att = carve<char>(c, es * R * D);
+    char* ffm = carve<char>(c, es * R * FF);
+    float* pred = carve<float>(c, R * MP);
+    int* kv_len = carve<int>(c, 2 * B);
+    const float* rope[4] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k};
+
+    KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
+    {
+        Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * R * (M + CD) / 2 + (double)es * R * KP, st);
+        KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, B * N, M, CD, 0, st, &m__));
+    }
+    for (int s = step0; s < step0 + n_steps; ++s) {
+        if (s != step0) {
+            Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * B * N * M + 2.0 * es * B * N * M, st);
+            KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, B * N, M, CD, 1, st, &m__));
+        }
+        // input embedding: proj, then conv position embedding (two grouped convs + Mish) + residual
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_NONE_, xcat, KP, "input.proj.weight", KP, "input.proj.bias", h, D, (int)R, D, KP, st,
+                         nullptr, 0, nullptr, 0, 0, 2.0 * R * D * (M + CD))) return r;
+        for (int j = 1; j <= 2; ++j) {
+            vv_posconv_args a{};
+            a.dtype = c->dt; a.out_dtype = (j == 1) ? c->dt : VV_DTYPE_F32;
+            a.in = (j == 1) ? h : h2; a.ld_in = D;
+            const std::string wn = "input.pos_conv" + std::to_string(j) + ".weight", bn = "input.pos_conv" + std::to_string(j) + ".bias";
+            a.W = c->W(wn); a.bias = c->Wf(bn);
+            a.out = (j == 1) ? (void*)h2 : (void*)xres; a.ld_out = D;
+            a.resid = (j == 2) ? h : nullptr; a.ld_resid = D;
+            a.n_seq = 2 * B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * B; a.seq_len = kv_len;
+            Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
+            KCHK(c, vvk_posconv(&a, st, &m__));
+        }
+        for (int l = 0; l < g.depth; ++l) {
+            const float* mod = c->modtab + ((size_t)l * S + s) * 6 * D;
+            const std::string qkvw = blk(l, ".attn.qkv.weight"), qkvb = blk(l, ".attn.qkv.bias"), ow = blk(l, ".attn.out.weight"),
+                              ob = blk(l, ".attn.out.bias"), f1w = blk(l, ".ff1.weight"), f1b = blk(l, ".ff1.bias"),
+                              f2w = blk(l, ".ff2.weight"), f2b = blk(l, ".ff2.bias");
+            vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
+            a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
+            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D)) return r;
+            {
+                vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
+                t.heads = g.heads; t.dim = D; t.kv_len = kv_len;
+                Prof p(c, VV_PROF_ATTN, 4.0 * 2 * B * g.heads * (double)N * N * 64, (double)es * R * 4 * D, st);
+                KCHK(c, vvk_attention(&t, st, &m__));
+            }
+            if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_GATE_RES, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), xres, D, (int)R, D, D, st, mod + 2 * D)) return r;
+            a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
+            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
+            if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_GATE_RES, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), xres, D, (int)R, D, FF, st, mod + 5 * D)) return r;
+        }
+        {
+            const float* fm = c->fintab + (size_t)s * 2 * D;
+            vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
+            a.w = fm; a.b = fm + D;                          // scale, shift
+            Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st);
+            KCHK(c, vvk_ln_mod(&a, st, &m__));
+        }
+        if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, h, D, "final.proj.weight", D, "final.proj.bias", pred, MP, (int)R, MP, D, st,
+                         nullptr, M, nullptr, 0, 0, 2.0 * R * D * M)) return r;
+        {
+            Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * B * N * M, st);
+            KCHK(c, vvk_cfg_euler(x, pred, MP, B * N, M, g.cfg_strength, c->dt_host[s], st, &m__));
+        }
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------- decode
+int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
+              int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream) {
+    if (!c) return -22;
+    if (!c->finalized) return c->fail(-1, "vv_decode: weights not finalized");
+    if (B < 1 || N < 1 || !x || !ref_len || !seq_len || !pcm || !pcm_len || t_gen_max < 1 || t_gen_max > N)
+        return c->fail(-22, "vv_decode: bad arguments");
+    const vv_model_cfg& g = c->cfg;
+    if (ld_pcm < t_gen_max * g.hop_length) return c->fail(-22, "vv_decode: ld_pcm too small");
+    hipSetDevice(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = g.n_mel, nu = g.voc_n_up;
+    // buffer plan
+    std::vector<int> Ts(nu + 1), Cs(nu + 1);
+    Ts[0] = t_gen_max; Cs[0] = g.voc_pre_ch;
+    size_t big = 0;
+    for (int s = 0; s < nu; ++s) { Ts[s + 1] = Ts[s] * g.voc_up_rates[s]; Cs[s + 1] = Cs[s] / 2; big = std::max(big, (size_t)Cs[s + 1] * Ts[s + 1]); }
+    big = std::max(big, (size_t)Cs[0] * Ts[0]);
+    Need nd; nd.add(4ull * B * M * Ts[0]);
+    for (int i = 0; i < 5; ++i) nd.add(4ull * B * big);
+    nd.add(4ull * (nu + 1) * B);
+    if (int r = ensure_ws(c, nd.b)) return r;
+    float* v0 = carve<float>(c, (size_t)B * M * Ts[0]);
+    float* buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = carve<float>(c, (size_t)B * big);
+    int* lens = carve<int>(c, (size_t)(nu + 1) * B);
+
+    KCHK(c, vvk_decode_len(seq_len, ref_len, lens, B, nu + 1, c->d_mult, st, &m__));
+    HIPCHK(c, hipMemcpyAsync(pcm_len, lens + (size_t)nu * B, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+    {
+        Prof p(c, VV_PROF_ELEMWISE, 0, 8.0 * B * M * Ts[0], st);
+        KCHK(c, vvk_mel_slice(x, B, N, M, ref_len, seq_len, v0, Ts[0], st, &m__));
+    }
+    auto conv = [&](const float* in, const std::string& name, float* out, const float* resid, int Cin, int Cout, int T_in, int T_out, int KW,
+                    int dil, int up, float pre_slope, float scale, int accumulate, const int* len_in) -> int {
+        vv_conv_args a{};
+        a.in = in; a.W = c->Wf(name + ".weight"); a.bias = c->Wf(name + ".bias"); a.out = out; a.resid = resid;
+        a.B = B; a.Cin = Cin; a.Cout = Cout; a.T_in = T_in; a.T_out = T_out; a.KW = KW; a.dil = dil; a.transposed = up > 0; a.up = up;
+        a.rows_total = up > 0 ? Cout * up : Cout; a.rows_pad = pad_to(a.rows_total, 64); a.accumulate = accumulate;
+        a.pre_slope = pre_slope; a.out_scale = scale; a.len_in = len_in;
+        const double taps = up > 0 ? 2.0 : (double)KW;
+        Prof p(c, VV_PROF_VOC_CONV, 2.0 * B * (double)T_out * Cout * Cin * taps,
+               4.0 * B * ((double)Cin * T_in + (double)Cout * T_out * (1 + (resid ? 1 : 0) + (accumulate ? 1 : 0))), st);
+        const char* m = "";
+        int r = vvk_conv(&a, st, &m);
+        if (r) return c->fail(r, "%s (%s)", m, name.c_str());
+        return 0;
+    };
+    if (int r = conv(v0, "voc.pre", buf[0], nullptr, M, Cs[0], Ts[0], Ts[0], g.voc_pre_k, 1, 0, 1.0f, 1.0f, 0, lens)) return r;
+    float* cur = buf[0];
+    float* up_out = buf[1];
+    for (int s = 0; s < nu; ++s) {
+        const int C = Cs[s + 1], T = Ts[s + 1];
+        const int* len_s = lens + (size_t)(s + 1) * B;
+        if (int r = conv(cur, "voc.up." + std::to_string(s), up_out, nullptr, Cs[s], C, Ts[s], T, 2, 1, g.voc_up_rates[s], g.voc_lrelu, 1.0f, 0, lens + (size_t)s * B)) return r;
+        // MRF: acc = (1/n_res) * sum_a resblock_a(up_out)
+        float* acc = cur;                                   // previous stage input is dead now
+        float* t1 = (up_out == buf[1]) ? buf[2] : buf[1];
+        float* ya = buf[3];
+        float* yb = buf[4];
+        const float inv = 1.0f / (float)g.voc_n_res;
+        for (int a = 0; a < g.voc_n_res; ++a) {
+            const float* y = up_out;
+            for (int b = 0; b < g.voc_n_dil; ++b) {
+                const std::string q = "voc.res." + std::to_string(s) + "." + std::to_string(a) + "." + std::to_string(b);
+                if (int r = conv(y, q + ".conv1", t1, nullptr, C, C, T, T, g.voc_res_kernels[a], g.voc_res_dilations[b], 0, g.voc_lrelu, 1.0f, 0, len_s)) return r;
+                const bool last = b == g.voc_n_dil - 1;
+                float* dst = last ? acc : ((y == ya) ? yb : ya);
+                if (int r = conv(t1, q + ".conv2", dst, y, C, C, T, T, g.voc_res_kernels[a], 1, 0, g.voc_lrelu, last ? inv : 1.0f, last && a > 0, len_s)) return r;
+                y = dst;
+            }
+        }
+        // rotate: acc becomes the next stage input; up_out buffer is free
+        float* old_up = up_out;
+        cur = acc;
+        up_out = old_up;
+        // make sure next up_out differs from cur (it does: acc was the previous cur)
+    }
+    {
+        const int C = Cs[nu], T = Ts[nu];
+        Prof p(c, VV_PROF_VOC_POST, 2.0 * B * (double)T * C * g.voc_post_k, 4.0 * B * (double)C * T + 2.0 * B * T, st);
+        KCHK(c, vvk_conv_post(cur, c->Wf("voc.post.weight"), c->post_bias, pcm, ld_pcm, wave_f32, B, C, T, g.voc_post_k, 0.01f,
+                              lens + (size_t)nu * B, st, &m__));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+int vv_prof_enable(vv_ctx* c, int on) {
+    if (!c) return -22;
+    c->prof = on != 0;
+    return 0;
+}
+int vv_prof_collect(vv_ctx* c, int64_t* launches, double* ms, double* flops, double* bytes) {
+    if (!c) return -22;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipDeviceSynchronize());
+    for (auto& r : c->recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) c->p_ms[r.cls] += t;
+        c->pool.push_back(r.a); c->pool.push_back(r.b);
+    }
+    c->recs.clear();
+    for (int i = 0; i < VV_PROF_NCLASS; ++i) {
+        if (launches) launches[i] = c->p_launch[i];
+        if (ms) ms[i] = c->p_ms[i];
+        if (flops) flops[i] = c->p_flops[i];
+        if (bytes) bytes[i] = c->p_bytes[i];
+        c->p_launch[i] = 0; c->p_ms[i] = 0; c->p_flops[i] = 0; c->p_bytes[i] = 0;
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------------- single-kernel entries
+#define SINGLE(ctx, call)                                     \
+    do {                                                      \
+        if (!(ctx)) return -22;                               \
+        hipSetDevice((ctx)->device);                          \
+        const char* m__ = "";                                 \
+        int r__ = (call);                                     \
+        if (r__) return (ctx)->fail(r__, "%s", m__);          \
+        return 0;                                             \
+    } while (0)
+
+int vv_gemm(vv_ctx* c, const vv_gemm_args* a, void* st) { SINGLE(c, vvk_gemm(a, (hipStream_t)st, &m__)); }
+int vv_attention(vv_ctx* c, const vv_attn_args* a, void* st) { SINGLE(c, vvk_attention(a, (hipStream_t)st, &m__)); }
+int vv_layernorm(vv_ctx* c, const vv_ln_args* a, void* st) { SINGLE(c, vvk_ln_mod(a, (hipStream_t)st, &m__)); }
+int vv_posconv(vv_ctx* c, const vv_posconv_args* a, void* st) { SINGLE(c, vvk_posconv(a, (hipStream_t)st, &m__)); }
+int vv_conv1d(vv_ctx* c, const vv_conv_args* a, void* st) { SINGLE(c, vvk_conv(a, (hipStream_t)st, &m__)); }
+int vv_conv_post(vv_ctx* c, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T,
+                 int KW, float pre_slope, const int32_t* len_in, void* st) {
+    SINGLE(c, vvk_conv_post(in, w, bias, pcm, ld_pcm, wave_f32, B, C, T, KW, pre_slope, len_in, (hipStream_t)st, &m__));
+}
+int vv_mel(vv_ctx* c, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max, void* st) {
+    if (!c) return -22;
+    if (!c->W("const.window") || !c->W("const.tw_cos") || !c->W("const.tw_sin") || !c->W("const.mel_fb"))
+        return c->fail(-2, "vv_mel: constant tables not bound");
+    SINGLE(c, vvk_mel(audio, ld_audio, audio_len, c->Wf("const.window"), c->Wf("const.tw_cos"), c->Wf("const.tw_sin"), c->Wf("const.mel_fb"),
+                      mel, B, F_max, c->cfg.n_fft, c->cfg.hop_length, c->cfg.n_mel, (hipStream_t)st, &m__));
+}
+int vv_cfg_euler(vv_ctx* c, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* st) {
+    SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, (hipStream_t)st, &m__));
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// K8: flash-style attention forward for gfx950, head_dim 64, key-padding mask by length.
+//
+// Q/K/V live in the fused projection buffer [rows][3*D] (q | k | v), RoPE and the softmax scale
+// already applied by the QKV GEMM epilogue.  One workgroup = 4 waves = 128 queries of one
+// (sequence, head); each wave owns 32 queries and the whole 64-wide head.  K/V tiles of 64 keys
+// stream into a double-buffered LDS ring by LDS-DMA (global_load_lds_dwordx4).
+//
+// The score product is computed swapped, S^T = K Q^T (MFMA A = K rows, B = Q rows), so the key
+// index lands on the accumulator registers and the query on the lane: the online-softmax row
+// max / row sum are in-lane (plus one cross-half exchange), the rescale of O is a per-lane
+// scalar, and the exponentiated tile is already the B operand of O^T += V^T P^T with no LDS
+// round trip.  bf16: V^T fragments come from the row-major V tile through the gfx950 transposed
+// LDS read (ds_read_b64_tr_b16).  fp32: exact f32 MFMA (32x32x2), V read column-wise (ds_read_b32).
+#include "vv_common.h"
+#include "vv_kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ------------------------------------------------------------------------------------ bf16
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
+                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
+    kv_len = max(1, min(kv_len, seq_n));
+
+    const bf16* Qp = qkv + (size_t)seq * seq_n * ld + head * 64;
+    const bf16* Kp = Qp + D;
+    const bf16* Vp = Qp + 2 * D;
+
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = min(q0 + r32, seq_n - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
+
+    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * 16384;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = wave * 2 + u;
+            const int row = q * 8 + (lane >> 3);
+            const int key = min(kt * 64 + row, seq_n - 1);
+            const int p = lane & 7;
+            const int ck = p ^ ((row >> 1) & 7);              // swz128 (row reads, ds_read_b128)
+            const int cv = p ^ (((row >> 1) & 1) << 2);       // V: conflict-free transposed reads
+            glds16(Kp + (size_t)key * ld + ck * 8, base + q * 1024);
+            glds16(Vp + (size_t)key * ld + cv * 8, base + 8192 + q * 1024);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // transposed-read lane constants: 16-lane group g reads a 4-key x 16-d block
+    const int tr_grp = (lane >> 4) & 1, tr_i = lane & 15, tr_q = tr_i >> 2, tr_p = tr_i & 3;
+
+    const int n_tiles = (kv_len + 63) / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+        const char* sK = smem + (kt & 1) * 16384;
+        const char* sV = sK + 8192;
+
+        // ---- S^T = K Q^T : s[kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+            }
+        }
+        const int kbase = kt * 64;
+        if (kbase + 64 > kv_len) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= kv_len) s[kb][r] = NEG_BIG;
+                }
+        }
+        // ---- online softmax (query on the lane; the other half-wave holds the other 32 keys)
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+        m_run = m_new;
+        const float msc = m_new * LOG2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(fmaf(s[kb][r], LOG2E, -msc));
+                psum += p;
+                s[kb][r] = p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[kb][8 * st + j];
+                const int key0 = kb * 32 + 16 * st + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int c = dt * 4 + 2 * tr_grp + (tr_p >> 1);
+                    const int row0 = key0 + tr_q, row1 = row0 + 8;
+                    const char* a0 = sV + row0 * 128 + ((c ^ (((row0 >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
+                    const char* a1 = sV + row1 * 128 + ((c ^ (((row1 >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
+                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r32;
+    if (q < seq_n) {
+        bf16* op = out + ((size_t)seq * seq_n + q) * ldo + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                store4<bf16>(op + d0, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                             o[dt][4 * g + 3] * inv);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ fp32
+__global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
+                                                          int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32768];   // per stage: K 16 KiB | V 16 KiB (256-B rows)
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
+    kv_len = max(1, min(kv_len, seq_n));
+
+    const float* Qp = qkv + (size_t)seq * seq_n * ld + head * 64;
+    const float* Kp = Qp + D;
+    const float* Vp = Qp + 2 * D;
+
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = min(q0 + r32, seq_n - 1);
+    f32x4 qf[8];   // lane half h takes d = 8kk + 4h + j: the same k pairing as the K fragment below
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const f32x4*)(Qp + (size_t)qrow * ld + kk * 8 + h * 4);
+
+    // staging: 16 pieces of 4 rows x 256 B per tile; wave w issues pieces 4w..4w+3 of K and V
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * 32768;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wave * 4 + u;
+            const int row = q * 4 + (lane >> 4);
+            const int key = min(kt * 64 + row, seq_n - 1);
+            const int p = lane & 15;
+            const int ck = p ^ (row & 15);
+            glds16(Kp + (size_t)key * ld + ck * 4, base + q * 1024);
+            glds16(Vp + (size_t)key * ld + p * 4, base + 16384 + q * 1024);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    const int n_tiles = (kv_len + 63) / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+        const char* sK = smem + (kt & 1) * 32768;
+        const char* sV = sK + 16384;
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            const int row = kb * 32 + r32;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const f32x4 kf = *(const f32x4*)(sK + row * 256 + (((2 * kk + h) ^ (row & 15)) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[kk][j], s[kb], 0, 0, 0);
+            }
+        }
+        const int kbase = kt * 64;
+        if (kbase + 64 > kv_len) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= kv_len) s[kb][r] = NEG_BIG;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        m_run = m_new;
+        const float msc = m_new * LOG2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(fmaf(s[kb][r], LOG2E, -msc));
+                psum += p;
+                s[kb][r] = p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // O^T += V^T P^T, two keys per MFMA: lane half h contributes key (i&3)+8(i>>2)+4h of block kb
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const float vf = *(const float*)(sV + key * 256 + (dt * 32 + r32) * 4);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[kb][i], o[dt], 0, 0, 0);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r32;
+    if (q < seq_n) {
+        float* op = out + ((size_t)seq * seq_n + q) * ldo + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                store4<float>(op + d0, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                              o[dt][4 * g + 3] * inv);
+            }
+    }
+}
+
+}  // namespace
+
+int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
+    if (a->n_seq <= 0 || a->seq_n <= 0 || a->heads <= 0) { *err = "attention: empty shape"; return -22; }
+    if (a->dim != a->heads * 64) { *err = "attention: head_dim must be 64"; return -22; }
+    const int esz = a->dtype == VV_BF16 ? 2 : 4;
+    if (((size_t)a->ld_qkv * esz) % 16 || ((size_t)a->ld_out * esz) % 8 || ((uintptr_t)a->qkv % 16) || ((uintptr_t)a->out % 16)) {
+        *err = "attention: qkv/out must be 16-byte aligned"; return -22;
+    }
+    if (a->ld_qkv < 3 * a->dim || a->ld_out < a->dim) { *err = "attention: leading dimensions too small"; return -22; }
+    dim3 grid((a->seq_n + 127) / 128, a->heads, a->n_seq);
+    if (a->dtype == VV_BF16)
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len);
+    else
+        attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}

@@ -1,0 +1,365 @@
+// HBM-bound kernels of the acoustic path: K4 LayerNorm/AdaLN-modulate, K2 conditioning pack,
+// K9 CFG+Euler, text-side embedding gather / depthwise conv / GRN, and the tiny time-grid helpers.
+// All are wave64-native: 16-byte vector loads, wave shuffles for row reductions, no LDS unless a
+// cross-wave reduction is needed.
+#include "vv_common.h"
+#include "vv_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------- K4: y = LN(x) * (w [+1]) + b
+// One wave per row, the row cached in registers (D <= 1024): one HBM read, one write.
+template <typename To>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int ldx, To* __restrict__ y, int ldy,
+                                                     int R, int D, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int add_one, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int n4 = D >> 2;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < n4) {
+            v[i] = *(const float4*)(xr + c * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < n4) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float one = add_one ? 1.0f : 0.0f;
+    To* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < n4) {
+            float4 ww = w ? *(const float4*)(w + c * 4) : make_float4(1.f - one, 1.f - one, 1.f - one, 1.f - one);
+            float4 bv = b ? *(const float4*)(b + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            store4<To>(yr + c * 4, (v[i].x - mean) * rstd * (ww.x + one) + bv.x, (v[i].y - mean) * rstd * (ww.y + one) + bv.y,
+                       (v[i].z - mean) * rstd * (ww.z + one) + bv.z, (v[i].w - mean) * rstd * (ww.w + one) + bv.w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K2: pack [x | cond | text | 0-pad] rows
+// Rows are [branch][b][t]; branch 0 reads cat, branch 1 reads cat_drop.  only_x rewrites just the
+// n_mel state columns (the per-step part); the conditioning columns are written once per call.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_cat_kernel(const float* __restrict__ x, const float* __restrict__ cat,
+                                                       const float* __restrict__ cat_drop, T* __restrict__ out, int ldo,
+                                                       int BN, int n_mel, int cond_dim, int only_x) {
+    const int cols4 = (only_x ? n_mel : ldo) >> 2;
+    const size_t total = (size_t)2 * BN * cols4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cols4) * 4;
+        const size_t row = i / cols4;
+        const size_t bt = row >= (size_t)BN ? row - BN : row;
+        float4 v;
+        if (c < n_mel) v = *(const float4*)(x + bt * n_mel + c);
+        else if (c < n_mel + cond_dim) v = *(const float4*)((row >= (size_t)BN ? cat_drop : cat) + bt * cond_dim + (c - n_mel));
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        store4<T>(out + row * ldo + c, v.x, v.y, v.z, v.w);
+    }
+}
+
+// ---------------------------------------------------------------- K9: x += dt * (pc + cfg (pc - pu))
+__global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ x, const float* __restrict__ pred, int ldp,
+                                                        int BN, int n_mel, float cfg, float dt) {
+    const int c4 = n_mel >> 2;
+    const size_t total = (size_t)BN * c4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const size_t row = i / c4;
+        const float4 pc = *(const float4*)(pred + row * ldp + c);
+        const float4 pu = *(const float4*)(pred + (row + BN) * ldp + c);
+        float4 xv = *(float4*)(x + row * n_mel + c);
+        xv.x += dt * (pc.x + (pc.x - pu.x) * cfg);
+        xv.y += dt * (pc.y + (pc.y - pu.y) * cfg);
+        xv.z += dt * (pc.z + (pc.z - pu.z) * cfg);
+        xv.w += dt * (pc.w + (pc.w - pu.w) * cfg);
+        *(float4*)(x + row * n_mel + c) = xv;
+    }
+}
+
+// ---------------------------------------------------------------- text: embed gather + position table
+// Sequence s in [0, 2B): b = s % B, drop branch when s >= B (all filler ids).  Token t of the
+// text is id+1; beyond the text (or the sequence) the filler id 0.
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ ids, int ld_ids,
+                                                         const int* __restrict__ text_len, const float* __restrict__ emb,
+                                                         const float* __restrict__ pos, float* __restrict__ out, int B,
+                                                         int N, int Dt, int vocab_rows) {
+    const int c4 = Dt >> 2;
+    const size_t total = (size_t)2 * B * N * c4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const size_t row = i / c4;
+        const int t = (int)(row % N);
+        const int s = (int)(row / N);
+        const int b = s % B;
+        int id = 0;
+        if (s < B && t < text_len[b] && t < ld_ids) id = ids[(size_t)b * ld_ids + t] + 1;
+        id = min(max(id, 0), vocab_rows - 1);
+        const float4 e = *(const float4*)(emb + (size_t)id * Dt + c);
+        const float4 p = *(const float4*)(pos + (size_t)t * Dt + c);
+        *(float4*)(out + row * Dt + c) = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    }
+}
+
+// depthwise conv k=KW along tokens, token-major [seq][t][c]; zero beyond [0, len)
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     const float* __restrict__ w /*[C][KW]*/, const float* __restrict__ bias,
+                                                     const int* __restrict__ seq_len, int B, int n_seq, int N, int C, int KW) {
+    const int c4 = C >> 2;
+    const size_t total = (size_t)n_seq * N * c4;
+    const int pad = KW / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const size_t row = i / c4;
+        const int t = (int)(row % N);
+        const int s = (int)(row / N);
+        const int len = seq_len ? min(seq_len[s % B], N) : N;
+        float4 acc = *(const float4*)(bias + c);
+        for (int k = 0; k < KW; ++k) {
+            const int tt = t + k - pad;
+            if (tt < 0 || tt >= len) continue;
+            const float4 v = *(const float4*)(in + ((size_t)s * N + tt) * C + c);
+            acc.x += w[(c + 0) * KW + k] * v.x;
+            acc.y += w[(c + 1) * KW + k] * v.y;
+            acc.z += w[(c + 2) * KW + k] * v.z;
+            acc.w += w[(c + 3) * KW + k] * v.w;
+        }
+        *(float4*)(out + row * C + c) = acc;
+    }
+}
+
+// GRN statistics: sumsq[s][c] over valid tokens.  grid (C/64, n_seq), block 256 = 4 token phases x 64 channels
+template <typename T>
+__global__ __launch_bounds__(256) void grn_stats_kernel(const T* __restrict__ x, float* __restrict__ sumsq,
+                                                        const int* __restrict__ seq_len, int B, int N, int C) {
+    __shared__ float red[256];
+    const int s = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    const int len = seq_len ? min(seq_len[s % B], N) : N;
+    float acc = 0.f;
+    for (int t = ph; t < len; t += 4) {
+        const float v = to_f32<T>(x[((size_t)s * N + t) * C + c]);
+        acc += v * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0) sumsq[(size_t)s * C + c] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// GRN apply: y = gamma * (x * nx) + beta + x, nx = g / (mean_c g + 1e-6), g = sqrt(sumsq).  In place.
+template <typename T>
+__global__ __launch_bounds__(256) void grn_apply_kernel(T* __restrict__ x, const float* __restrict__ sumsq,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int N, int C, int rows_per_block) {
+    extern __shared__ float sc[];      // [C] scale = gamma*nx + 1
+    __shared__ float red[4];
+    const int s = blockIdx.y;
+    float part = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) part += sqrtf(sumsq[(size_t)s * C + c]);
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
+    for (int c = threadIdx.x; c < C; c += 256) sc[c] = gamma[c] * (sqrtf(sumsq[(size_t)s * C + c]) / (mean + 1e-6f)) + 1.0f;
+    __syncthreads();
+    const int t0 = blockIdx.x * rows_per_block;
+    const int c4 = C >> 2;
+    for (int i = threadIdx.x; i < rows_per_block * c4; i += 256) {
+        const int t = t0 + i / c4;
+        if (t >= N) break;
+        const int c = (i % c4) * 4;
+        T* p = x + ((size_t)s * N + t) * C + c;
+        const float4 v = load4<T>(p);
+        const float4 bb = *(const float4*)(beta + c);
+        store4<T>(p, v.x * sc[c] + bb.x, v.y * sc[c + 1] + bb.y, v.z * sc[c + 2] + bb.z, v.w * sc[c + 3] + bb.w);
+    }
+}
+
+// conditioning: cat[b][t] = [mel (t < ref_len) | text(b)], cat_drop[b][t] = [0 | text(B+b)]
+__global__ __launch_bounds__(256) void build_cat_kernel(const float* __restrict__ mel, int F_max,
+                                                        const int* __restrict__ ref_len, const float* __restrict__ text,
+                                                        float* __restrict__ cat, float* __restrict__ cat_drop, int B, int N,
+                                                        int n_mel, int Dt) {
+    const int cd = n_mel + Dt;
+    const int c4 = cd >> 2;
+    const size_t total = (size_t)B * N * c4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const size_t row = i / c4;
+        const int t = (int)(row % N);
+        const int b = (int)(row / N);
+        float4 v, vd;
+        if (c < n_mel) {
+            v = (t < ref_len[b] && t < F_max) ? *(const float4*)(mel + ((size_t)b * F_max + t) * n_mel + c)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            vd = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            v = *(const float4*)(text + row * Dt + (c - n_mel));
+            vd = *(const float4*)(text + ((size_t)B * N + row) * Dt + (c - n_mel));
+        }
+        *(float4*)(cat + row * cd + c) = v;
+        *(float4*)(cat_drop + row * cd + c) = vd;
+    }
+}
+
+// small integer helpers (lengths live on the device so that batches need no host round trip)
+__global__ void ref_len_kernel(const int* __restrict__ audio_len, int* __restrict__ ref_len, int B, int hop) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) ref_len[b] = audio_len[b] / hop + 1;      // reference core/tts_engine.py:55
+}
+__global__ void decode_len_kernel(const int* __restrict__ seq_len, const int* __restrict__ ref_len, int* __restrict__ lens,
+                                  int B, int n_levels, const int* __restrict__ mult) {
+    // lens[level][b] = max(seq_len - ref_len, 0) * mult[level]
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int tg = max(seq_len[b] - ref_len[b], 0);
+    for (int l = 0; l < n_levels; ++l) lens[l * B + b] = tg * mult[l];
+}
+__global__ void dup_len_kernel(const int* __restrict__ seq_len, int* __restrict__ out, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < B) { out[b] = seq_len[b]; out[B + b] = seq_len[b]; }
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(float* __restrict__ x, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        x[i] = v / (1.0f + expf(-v));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = *(const float4*)(in + i * 4);
+        store4<T>(out + i * 4, v.x, v.y, v.z, v.w);
+    }
+}
+
+inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 256 * 8); }
+
+}  // namespace
+
+#define VVK_CHECK_LAUNCH()                                               \
+    do {                                                                 \
+        hipError_t he__ = hipGetLastError();                             \
+        if (he__ != hipSuccess) { *err = hipGetErrorString(he__); return -5; } \
+    } while (0)
+
+int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
+    if (a->R <= 0) { *err = "ln: empty"; return -22; }
+    if (a->D % 4 || a->D > 1024 || a->ldx % 4 || a->ldy % 4) { *err = "ln: D must be a multiple of 4 and <= 1024"; return -22; }
+    const int grid = (a->R + 3) / 4;
+    if (a->out_dtype == VV_BF16)
+        ln_mod_kernel<bf16><<<grid, 256, 0, st>>>(a->x, a->ldx, (bf16*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps);
+    else
+        ln_mod_kernel<float><<<grid, 256, 0, st>>>(a->x, a->ldx, (float*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_pack_cat(int dtype, const float* x, const float* cat, const float* cat_drop, void* out, int ldo, int BN, int n_mel,
+                 int cond_dim, int only_x, hipStream_t st, const char** err) {
+    if (n_mel % 4 || cond_dim % 4 || ldo % 4 || ldo < n_mel + cond_dim) { *err = "pack_cat: bad widths"; return -22; }
+    const size_t total = (size_t)2 * BN * ((only_x ? n_mel : ldo) / 4);
+    if (dtype == VV_BF16)
+        pack_cat_kernel<bf16><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (bf16*)out, ldo, BN, n_mel, cond_dim, only_x);
+    else
+        pack_cat_kernel<float><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (float*)out, ldo, BN, n_mel, cond_dim, only_x);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_cfg_euler(float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, hipStream_t st, const char** err) {
+    if (n_mel % 4 || ldp % 4) { *err = "cfg_euler: widths must be multiples of 4"; return -22; }
+    cfg_euler_kernel<<<grid_for((size_t)BN * n_mel / 4), 256, 0, st>>>(x, pred, ldp, BN, n_mel, cfg, dt);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_text_embed(const int* ids, int ld_ids, const int* text_len, const float* emb, const float* pos, float* out, int B,
+                   int N, int Dt, int vocab_rows, hipStream_t st, const char** err) {
+    if (Dt % 4) { *err = "text_embed: Dt % 4"; return -22; }
+    text_embed_kernel<<<grid_for((size_t)2 * B * N * Dt / 4), 256, 0, st>>>(ids, ld_ids, text_len, emb, pos, out, B, N, Dt, vocab_rows);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_dwconv(const float* in, float* out, const float* w, const float* bias, const int* seq_len, int B, int n_seq, int N,
+               int C, int KW, hipStream_t st, const char** err) {
+    if (C % 4) { *err = "dwconv: C % 4"; return -22; }
+    dwconv_kernel<<<grid_for((size_t)n_seq * N * C / 4), 256, 0, st>>>(in, out, w, bias, seq_len, B, n_seq, N, C, KW);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_grn(int dtype, void* x, float* sumsq, const float* gamma, const float* beta, const int* seq_len, int B, int n_seq,
+            int N, int C, hipStream_t st, const char** err) {
+    if (C % 64 || C > 8192) { *err = "grn: C must be a multiple of 64"; return -22; }
+    dim3 g1(C / 64, n_seq);
+    const int rpb = 16;
+    dim3 g2((N + rpb - 1) / rpb, n_seq);
+    if (dtype == VV_BF16) {
+        grn_stats_kernel<bf16><<<g1, 256, 0, st>>>((const bf16*)x, sumsq, seq_len, B, N, C);
+        grn_apply_kernel<bf16><<<g2, 256, C * sizeof(float), st>>>((bf16*)x, sumsq, gamma, beta, N, C, rpb);
+    } else {
+        grn_stats_kernel<float><<<g1, 256, 0, st>>>((const float*)x, sumsq, seq_len, B, N, C);
+        grn_apply_kernel<float><<<g2, 256, C * sizeof(float), st>>>((float*)x, sumsq, gamma, beta, N, C, rpb);
+    }
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_build_cat(const float* mel, int F_max, const int* ref_len, const float* text, float* cat, float* cat_drop, int B, int N,
+                  int n_mel, int Dt, hipStream_t st, const char** err) {
+    if (n_mel % 4 || Dt % 4) { *err = "build_cat: widths % 4"; return -22; }
+    build_cat_kernel<<<grid_for((size_t)B * N * (n_mel + Dt) / 4), 256, 0, st>>>(mel, F_max, ref_len, text, cat, cat_drop, B, N, n_mel, Dt);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+
+int vvk_ref_len(const int* audio_len, int* ref_len, int B, int hop, hipStream_t st, const char** err) {
+    ref_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(audio_len, ref_len, B, hop);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int n_levels, const int* mult, hipStream_t st, const char** err) {
+    decode_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(seq_len, ref_len, lens, B, n_levels, mult);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err) {
+    dup_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(seq_len, out, B);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_silu(float* x, size_t n, hipStream_t st, const char** err) {
+    silu_kernel<<<grid_for(n), 256, 0, st>>>(x, n);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err) {
+    if (n % 4) { *err = "cast: n % 4"; return -22; }
+    if (dtype == VV_BF16) cast_kernel<bf16><<<grid_for(n / 4), 256, 0, st>>>(in, (bf16*)out, n / 4);
+    else cast_kernel<float><<<grid_for(n / 4), 256, 0, st>>>(in, (float*)out, n / 4);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,186 @@
+// K3: convolutional position embedding -- grouped Conv1d (k = 31, 64 channels per group) + Mish,
+// token-major activations [rows][D].  Per group this is an implicit GEMM with K = 31 * 64:
+//   out[t][co] = bias[co] + sum_kw sum_ci  W[g][kw][co][ci] * in[t + kw - pad][g*64 + ci]
+//
+// bf16: one workgroup = 128 tokens x 64 output channels of one (sequence, group).  The
+// (128 + 30)-token input window is staged ONCE in LDS (128-byte rows, swz128 image) with zero fill
+// outside [0, len); every tap re-reads it at a row offset, so HBM sees each activation once.
+// Weight fragments (8 KiB per tap, shared by every workgroup of the group) come straight from
+// L2 into registers, software-prefetched one tap ahead.  MFMA v_mfma_f32_16x16x32_bf16 with the
+// transposed product (A = weights, B = tokens) so a lane owns 4 consecutive channels of a token.
+//
+// fp32: exact-f32 VALU kernel for the numerics configuration (not the throughput path).
+#include "vv_common.h"
+#include "vv_kernels.h"
+
+namespace {
+
+constexpr int PC_TOK = 128;
+
+template <typename To>
+__global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16* __restrict__ in, int ldi,
+                                                              const bf16* __restrict__ W /*[G][KW][64co][64ci]*/,
+                                                              const float* __restrict__ bias, To* __restrict__ out, int ldo,
+                                                              const bf16* __restrict__ resid, int ldr, int seq_n,
+                                                              const int* __restrict__ seq_len, int B, int KW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // (PC_TOK + KW - 1) rows x 128 B
+    const int g = blockIdx.y, seq = blockIdx.z;
+    const int t0 = blockIdx.x * PC_TOK;
+    const int pad = KW / 2;
+    const int len = seq_len ? min(seq_len[seq % B], seq_n) : seq_n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rows = PC_TOK + KW - 1;
+
+    // ---- stage the window (register path: needs zero fill at the sequence edges)
+    for (int i = threadIdx.x; i < rows * 8; i += 256) {
+        const int r = i >> 3, c = i & 7;
+        const int t = t0 + r - pad;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < len) v = *(const uint4*)(in + ((size_t)seq * seq_n + t) * ldi + g * 64 + c * 8);
+        *(uint4*)(smem + swz128(r, c)) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, cq = lane >> 4;
+    const bf16* wg = W + (size_t)g * KW * 4096 + (size_t)r16 * 64 + cq * 8;   // + kw*4096 + ni*1024 + ks*32
+
+    bf16x8 wf[2][4], wn[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) wf[ks][ni] = *(const bf16x8*)(wg + ni * 1024 + ks * 32);
+
+    for (int kw = 0; kw < KW; ++kw) {
+        if (kw + 1 < KW) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) wn[ks][ni] = *(const bf16x8*)(wg + (size_t)(kw + 1) * 4096 + ni * 1024 + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                xf[mi] = *(const bf16x8*)(smem + swz128(wave * 32 + mi * 16 + r16 + kw, ks * 4 + cq));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) wf[ks][ni] = wn[ks][ni];
+    }
+
+    // D[co_local = cq*4 + j][token_local = r16]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int t = t0 + wave * 32 + mi * 16 + r16;
+        if (t >= seq_n) continue;
+        const size_t row = (size_t)seq * seq_n + t;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int co = g * 64 + ni * 16 + cq * 4;
+            const float4 b = *(const float4*)(bias + co);
+            float v0 = act_apply(acc[ni][mi][0] + b.x, VV_ACT_MISH), v1 = act_apply(acc[ni][mi][1] + b.y, VV_ACT_MISH);
+            float v2 = act_apply(acc[ni][mi][2] + b.z, VV_ACT_MISH), v3 = act_apply(acc[ni][mi][3] + b.w, VV_ACT_MISH);
+            if (resid) {
+                const float4 r = load4<bf16>(resid + row * ldr + co);
+                v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+            }
+            store4<To>(out + row * ldo + co, v0, v1, v2, v3);
+        }
+    }
+}
+
+// fp32 VALU version: block = 64 tokens x 64 channels of a group; thread = 1 channel x 16 tokens.
+// Weights in [G][KW][ci][co] order so a wave reads 64 consecutive channels per (kw, ci).
+constexpr int PF_TOK = 64;
+__global__ __launch_bounds__(256) void posconv_f32_kernel(const float* __restrict__ in, int ldi,
+                                                          const float* __restrict__ W /*[G][KW][64ci][64co]*/,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                          const float* __restrict__ resid, int ldr, int seq_n,
+                                                          const int* __restrict__ seq_len, int B, int KW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // (PF_TOK + KW - 1) rows x 64 floats
+    float* xs = (float*)smem;
+    const int g = blockIdx.y, seq = blockIdx.z;
+    const int t0 = blockIdx.x * PF_TOK;
+    const int pad = KW / 2;
+    const int len = seq_len ? min(seq_len[seq % B], seq_n) : seq_n;
+    const int rows = PF_TOK + KW - 1;
+    for (int i = threadIdx.x; i < rows * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        const int t = t0 + r - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < len) v = *(const float4*)(in + ((size_t)seq * seq_n + t) * ldi + g * 64 + c * 4);
+        *(float4*)(xs + r * 64 + c * 4) = v;
+    }
+    __syncthreads();
+    const int co = threadIdx.x & 63, tg = threadIdx.x >> 6;   // tokens tg*16 .. tg*16+15
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* wp = W + (size_t)g * KW * 4096 + co;
+    for (int kw = 0; kw < KW; ++kw) {
+        for (int ci = 0; ci < 64; ci += 4) {
+            const float w0 = wp[(kw * 64 + ci + 0) * 64], w1 = wp[(kw * 64 + ci + 1) * 64];
+            const float w2 = wp[(kw * 64 + ci + 2) * 64], w3 = wp[(kw * 64 + ci + 3) * 64];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 x = *(const float4*)(xs + (tg * 16 + i + kw) * 64 + ci);   // wave-uniform address: broadcast
+                acc[i] = fmaf(w0, x.x, acc[i]);
+                acc[i] = fmaf(w1, x.y, acc[i]);
+                acc[i] = fmaf(w2, x.z, acc[i]);
+                acc[i] = fmaf(w3, x.w, acc[i]);
+            }
+        }
+    }
+    const float b = bias[g * 64 + co];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int t = t0 + tg * 16 + i;
+        if (t >= seq_n) break;
+        const size_t row = (size_t)seq * seq_n + t;
+        float v = act_apply(acc[i] + b, VV_ACT_MISH);
+        if (resid) v += resid[row * ldr + g * 64 + co];
+        out[row * ldo + g * 64 + co] = v;
+    }
+}
+
+}  // namespace
+
+int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err) {
+    if (a->groups <= 0 || a->n_seq <= 0 || a->seq_n <= 0) { *err = "posconv: empty shape"; return -22; }
+    if (a->KW < 1 || a->KW > 63 || !(a->KW & 1)) { *err = "posconv: odd kernel width expected"; return -22; }
+    if (a->ld_in < a->groups * 64 || a->ld_out < a->groups * 64) { *err = "posconv: 64 channels per group expected"; return -22; }
+    if (a->dtype == VV_BF16) {
+        if ((a->ld_in * 2) % 16 || (uintptr_t)a->in % 16 || (uintptr_t)a->W % 16) { *err = "posconv: alignment"; return -22; }
+        dim3 grid((a->seq_n + PC_TOK - 1) / PC_TOK, a->groups, a->n_seq);
+        const size_t lds = (size_t)(PC_TOK + a->KW - 1) * 128;
+        if (a->out_dtype == VV_BF16)
+            posconv_bf16_kernel<bf16><<<grid, 256, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (bf16*)a->out,
+                                                              a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+        else
+            posconv_bf16_kernel<float><<<grid, 256, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (float*)a->out,
+                                                               a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+    } else {
+        if (a->out_dtype != VV_F32) { *err = "posconv: f32 path writes f32"; return -22; }
+        if ((a->ld_in * 4) % 16 || (uintptr_t)a->in % 16) { *err = "posconv: alignment"; return -22; }
+        dim3 grid((a->seq_n + PF_TOK - 1) / PF_TOK, a->groups, a->n_seq);
+        const size_t lds = (size_t)(PF_TOK + a->KW - 1) * 256;
+        posconv_f32_kernel<<<grid, 256, lds, st>>>((const float*)a->in, a->ld_in, (const float*)a->W, a->bias, (float*)a->out, a->ld_out,
+                                                   (const float*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+    }
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}

@@ -1,0 +1,256 @@
+// K10-K13: vocoder kernels (fp32), channel-major activations [B][C][T] (T contiguous).
+//
+// conv1d / ConvTranspose1d are ONE implicit-GEMM kernel on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32):  D[row][col = time] = sum_k Wt[k][row] * X[k][time + off(k)].
+//   * Conv1d (KW taps, dilation d):   row = co,           off(kw) = kw*d - d*(KW-1)/2
+//   * ConvTranspose1d (stride u, kernel 2u, pad u/2) in polyphase form, no zero-stuffing:
+//        row = co*u + p,  taps j in {0,1}: in[q - j] * W[ci][co][p + j*u],  out time = q*u + p - u/2
+// A workgroup owns 64 rows x 256 time steps; the K loop walks input channels 8 at a time, staging
+// the 8-channel input window (with the fused input LeakyReLU and zero fill outside [0,len)) and
+// the matching weight slab in LDS.  MFMA lane half h takes channel 2j+h, so both halves read
+// conflict-free consecutive-time / consecutive-row LDS words.  Epilogue fuses bias, residual add,
+// the 1/3 MRF average and accumulation across the three resblocks; stores are 128-byte segments.
+//
+// conv_post (K13): 32->1 channel k=7 conv + tanh + int16 quantisation, HBM-bound, LDS window.
+#include "vv_common.h"
+#include "vv_kernels.h"
+
+namespace {
+
+constexpr int VT = 256;       // time steps per workgroup
+constexpr int VR = 64;        // rows per workgroup
+constexpr int VCI = 8;        // input channels per K chunk
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
+
+// KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).
+template <int KW, bool TRANSPOSED>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt /*[Cin_pad][KW][rows_pad]*/,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           const float* __restrict__ resid, int Cin, int rows_total,
+                                                           int rows_pad, int T_in, int T_out, int Cout, int dil, int up,
+                                                           float pre_slope, float out_scale, int accumulate,
+                                                           const int* __restrict__ len_in) {
+    // halo: conv reads time + kw*dil - left; transposed reads q and q-1
+    const int left = TRANSPOSED ? 1 : dil * (KW - 1) / 2;
+    const int span = TRANSPOSED ? 1 : dil * (KW - 1);
+    const int xw = VT + span;                         // staged window width per channel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                         // [VCI][xw_pad]
+    const int xw_pad = (xw + 3) & ~3;
+    float* ws = xs + VCI * xw_pad;                    // [VCI][KW][VR]
+
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * VR;
+    const int q0 = blockIdx.x * VT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int lin = len_in ? min(len_in[b], T_in) : T_in;
+    const float* inb = in + (size_t)b * Cin * T_in;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int c0 = 0; c0 < Cin; c0 += VCI) {
+        __syncthreads();
+        // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 + i - left])
+        for (int i = threadIdx.x; i < VCI * xw; i += 256) {
+            const int c = i / xw, k = i - c * xw;
+            const int pos = q0 + k - left;
+            float v = 0.f;
+            if (c0 + c < Cin && pos >= 0 && pos < lin) v = lrelu(inb[(size_t)(c0 + c) * T_in + pos], pre_slope);
+            xs[c * xw_pad + k] = v;
+        }
+        // ---- stage the weight slab: ws[c][kw][r] = Wt[c0+c][kw][r0+r]   (padded, no masks)
+        for (int i = threadIdx.x; i < VCI * KW * (VR / 4); i += 256) {
+            const int r4 = i % (VR / 4), ck = i / (VR / 4);
+            *(float4*)(ws + ck * VR + r4 * 4) = *(const float4*)(Wt + ((size_t)c0 * KW + ck) * rows_pad + r0 + r4 * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VCI / 2; ++j) {
+            const int c = 2 * j + h;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int off = TRANSPOSED ? (left - kw) : kw * dil;          // window index = local time + off
+                float a[2], x[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = ws[(c * KW + kw) * VR + i * 32 + r32];
+                    x[i] = xs[c * xw_pad + wave * 64 + i * 32 + r32 + off];
+                }
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+                        acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], x[ti], acc[ri][ti], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32]
+    float* outb = out + (size_t)b * Cout * T_out;
+    const float* resb = resid ? resid + (size_t)b * Cout * T_out : nullptr;
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int q = q0 + wave * 64 + ti * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= rows_total) continue;
+                int co, t;
+                if (TRANSPOSED) { co = row / up; t = q * up + (row - co * up) - up / 2; }
+                else { co = row; t = q; }
+                if (t < 0 || t >= T_out) continue;
+                float v = acc[ri][ti][r] + bias[co];
+                const size_t o = (size_t)co * T_out + t;
+                if (resb) v += resb[o];
+                v *= out_scale;
+                if (accumulate) v += outb[o];
+                outb[o] = v;
+            }
+        }
+}
+
+// ---- K13: conv_post (C -> 1, k = KW) on lrelu(x), tanh, *32767, clip, truncate to int16
+template <int KW>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ in, const float* __restrict__ w /*[C][KW]*/,
+                                                        float bias, int16_t* __restrict__ pcm, int ld_pcm, float* __restrict__ wave_f32,
+                                                        int C, int T, float pre_slope, const int* __restrict__ len_in) {
+    constexpr int TP = 1024;                 // outputs per block (4 per thread)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                // [CH][TP + KW - 1] per channel chunk
+    constexpr int CH = 8;
+    constexpr int XW = TP + KW - 1;
+    constexpr int XWP = (XW + 3) & ~3;
+    float* wsm = xs + CH * XWP;              // [C][KW] (C <= 64)
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TP;
+    const int lin = len_in ? min(len_in[b], T) : T;
+    const float* inb = in + (size_t)b * C * T;
+    for (int i = threadIdx.x; i < C * KW; i += 256) wsm[i] = w[i];
+    float acc[4] = {bias, bias, bias, bias};
+    const int tl = threadIdx.x * 4;
+    for (int c0 = 0; c0 < C; c0 += CH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CH * XW; i += 256) {
+            const int c = i / XW, k = i - c * XW;
+            const int pos = t0 + k - KW / 2;
+            float v = 0.f;
+            if (c0 + c < C && pos >= 0 && pos < lin) v = lrelu(inb[(size_t)(c0 + c) * T + pos], pre_slope);
+            xs[c * XWP + k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (c0 + c >= C) break;
+            float xv[KW + 3];
+#pragma unroll
+            for (int k = 0; k < KW + 3; ++k) xv[k] = xs[c * XWP + tl + k];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const float wk = wsm[(c0 + c) * KW + k];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, xv[o + k], acc[o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int t = t0 + tl + o;
+        if (t >= T) break;
+        const float y = tanhf(acc[o]);
+        if (wave_f32) wave_f32[(size_t)b * T + t] = y;
+        const float s = fminf(fmaxf(y * 32767.0f, -32768.0f), 32767.0f);
+        pcm[(size_t)b * ld_pcm + t] = (int16_t)s;        // truncation toward zero, as an ONNX Cast does
+    }
+}
+
+// ---- K10: slice generated frames and transpose to channel-major: out[b][c][t] = x[b][ref_len+t][c]
+__global__ __launch_bounds__(256) void mel_slice_kernel(const float* __restrict__ x, int N, int n_mel,
+                                                        const int* __restrict__ ref_len, const int* __restrict__ seq_len,
+                                                        float* __restrict__ out, int T) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int rl = ref_len[b];
+    const int tg = max(min(seq_len[b], N) - rl, 0);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (t < tg && c < n_mel) v = x[((size_t)b * N + rl + t) * n_mel + c];
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < n_mel && t < T) out[((size_t)b * n_mel + c) * T + t] = tile[tx][i];
+    }
+}
+
+template <int KW, bool TR>
+int launch_conv(const vv_conv_args* a, hipStream_t st) {
+    const int span = TR ? 1 : a->dil * (KW - 1);
+    const int xw_pad = (VT + span + 3) & ~3;
+    const size_t lds = (size_t)(VCI * xw_pad + VCI * KW * VR) * sizeof(float);
+    const int q_total = TR ? a->T_in + 1 : a->T_out;
+    dim3 grid((q_total + VT - 1) / VT, a->rows_pad / VR, a->B);
+    conv_mfma_kernel<KW, TR><<<grid, 256, lds, st>>>(a->in, a->W, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad,
+                                                    a->T_in, a->T_out, a->Cout, a->dil, a->up, a->pre_slope, a->out_scale,
+                                                    a->accumulate, a->len_in);
+    return 0;
+}
+
+}  // namespace
+
+int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
+    if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->T_in <= 0 || a->T_out <= 0) { *err = "conv: empty shape"; return -22; }
+    if (a->rows_pad % VR || a->rows_pad < a->rows_total || ((uintptr_t)a->W % 16)) { *err = "conv: weight slab must be padded to 64 rows and 16-byte aligned"; return -22; }
+    if (a->transposed) {
+        if (a->KW != 2 || a->up < 2 || (a->up & 1) || a->rows_total != a->Cout * a->up || a->T_out != a->T_in * a->up) {
+            *err = "conv: transposed form needs kernel = 2*stride, even stride"; return -22;
+        }
+        launch_conv<2, true>(a, st);
+    } else {
+        if (a->rows_total != a->Cout || a->T_out != a->T_in || a->dil < 1 || a->dil * (a->KW - 1) > 64) { *err = "conv: bad conv shape"; return -22; }
+        switch (a->KW) {
+            case 3: launch_conv<3, false>(a, st); break;
+            case 7: launch_conv<7, false>(a, st); break;
+            case 11: launch_conv<11, false>(a, st); break;
+            default: *err = "conv: kernel width must be 3, 7 or 11"; return -22;
+        }
+    }
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
+int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T, int KW,
+                  float pre_slope, const int* len_in, hipStream_t st, const char** err) {
+    if (KW != 7 || C > 64 || C < 1) { *err = "conv_post: k=7 and C<=64 expected"; return -22; }
+    const size_t lds = (size_t)(8 * ((1024 + 6 + 3) & ~3) + C * 7) * sizeof(float);
+    dim3 grid((T + 1023) / 1024, B);
+    conv_post_kernel<7><<<grid, 256, lds, st>>>(in, w, bias, pcm, ld_pcm, wave_f32, C, T, pre_slope, len_in);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
+int vvk_mel_slice(const float* x, int B, int N, int n_mel, const int* ref_len, const int* seq_len, float* out, int T,
+                  hipStream_t st, const char** err) {
+    if (T <= 0) { *err = "mel_slice: empty"; return -22; }
+    dim3 grid((T + 31) / 32, (n_mel + 31) / 32, B);
+    mel_slice_kernel<<<grid, 256, 0, st>>>(x, N, n_mel, ref_len, seq_len, out, T);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}

@@ -1,0 +1,299 @@
+"""ctypes binding of libvvtts_hip.so (include/vvtts.h) and the device-resident synthesis driver.
+
+PyTorch is used only as plumbing here: it owns HBM tensors, the HIP stream and (multi-GPU) the
+RCCL broadcast.  Every arithmetic step of the hot path runs in the hand-written gfx950 kernels
+behind the C ABI.  There is NO CPU fallback: if the library or a GPU is missing this module
+raises, loudly (the oracle under oracle/ is test infrastructure and is never imported here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import pack
+from .model_spec import ModelSpec, time_grid
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvvtts_hip.so")
+
+VV_F32, VV_BF16 = 0, 1
+PROF_CLASSES = ["gemm", "attention", "norm", "posconv", "elementwise", "voc_conv", "voc_post", "mel", "text"]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class vv_model_cfg(C.Structure):
+    _fields_ = [
+        ("n_mel", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32), ("hop_length", C.c_int32),
+        ("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("ff_mult", C.c_int32),
+        ("text_dim", C.c_int32), ("text_layers", C.c_int32), ("text_conv_k", C.c_int32), ("text_ff_mult", C.c_int32),
+        ("vocab_rows", C.c_int32), ("pos_conv_k", C.c_int32), ("pos_conv_groups", C.c_int32), ("time_freq_dim", C.c_int32),
+        ("cfg_strength", C.c_float),
+        ("voc_pre_ch", C.c_int32), ("voc_pre_k", C.c_int32), ("voc_post_k", C.c_int32),
+        ("voc_n_up", C.c_int32), ("voc_up_rates", C.c_int32 * 8), ("voc_up_kernels", C.c_int32 * 8),
+        ("voc_n_res", C.c_int32), ("voc_res_kernels", C.c_int32 * 4),
+        ("voc_n_dil", C.c_int32), ("voc_res_dilations", C.c_int32 * 4),
+        ("voc_lrelu", C.c_float), ("max_pos", C.c_int32),
+    ]
+
+
+class vv_gemm_args(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("out_dtype", C.c_int32), ("mode", C.c_int32), ("act", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int32), ("W", C.c_void_p), ("ldw", C.c_int32), ("C", C.c_void_p), ("ldc", C.c_int32),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("bias", C.c_void_p), ("gate", C.c_void_p), ("cos_q", C.c_void_p), ("sin_q", C.c_void_p),
+                ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
+                ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32)]
+
+
+class vv_attn_args(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("qkv", C.c_void_p), ("ld_qkv", C.c_int32), ("out", C.c_void_p), ("ld_out", C.c_int32),
+                ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p)]
+
+
+class vv_ln_args(C.Structure):
+    _fields_ = [("out_dtype", C.c_int32), ("x", C.c_void_p), ("ldx", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
+                ("R", C.c_int32), ("D", C.c_int32), ("w", C.c_void_p), ("b", C.c_void_p), ("add_one", C.c_int32), ("eps", C.c_float)]
+
+
+class vv_posconv_args(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("out_dtype", C.c_int32), ("in_", C.c_void_p), ("ld_in", C.c_int32), ("W", C.c_void_p),
+                ("bias", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int32), ("resid", C.c_void_p), ("ld_resid", C.c_int32),
+                ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("groups", C.c_int32), ("KW", C.c_int32), ("B", C.c_int32),
+                ("seq_len", C.c_void_p)]
+
+
+class vv_conv_args(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("resid", C.c_void_p),
+                ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("T_in", C.c_int32), ("T_out", C.c_int32),
+                ("KW", C.c_int32), ("dil", C.c_int32), ("transposed", C.c_int32), ("up", C.c_int32),
+                ("rows_total", C.c_int32), ("rows_pad", C.c_int32), ("accumulate", C.c_int32),
+                ("pre_slope", C.c_float), ("out_scale", C.c_float), ("len_in", C.c_void_p)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "vv_version": (C.c_char_p, []),
+    "vv_last_error": (C.c_char_p, [C.c_void_p]),
+    "vv_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(vv_model_cfg), C.c_int]),
+    "vv_destroy": (None, [C.c_void_p]),
+    "vv_bind_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]),
+    "vv_finalize_weights": (C.c_int, [C.c_void_p]),
+    "vv_set_time_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vv_transformer_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vv_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vv_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "vv_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vv_gemm": (C.c_int, [C.c_void_p, C.POINTER(vv_gemm_args), C.c_void_p]),
+    "vv_attention": (C.c_int, [C.c_void_p, C.POINTER(vv_attn_args), C.c_void_p]),
+    "vv_layernorm": (C.c_int, [C.c_void_p, C.POINTER(vv_ln_args), C.c_void_p]),
+    "vv_posconv": (C.c_int, [C.c_void_p, C.POINTER(vv_posconv_args), C.c_void_p]),
+    "vv_conv1d": (C.c_int, [C.c_void_p, C.POINTER(vv_conv_args), C.c_void_p]),
+    "vv_conv_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "vv_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the in-tree library and type every export of include/vvtts.h.  No compute happens."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise HipUnavailable(f"{p} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+                                 "the HIP synthesis path has no CPU fallback")
+        lib = C.CDLL(p)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)          # AttributeError if an export is missing
+            fn.restype, fn.argtypes = res, args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def cfg_from_spec(spec: ModelSpec) -> vv_model_cfg:
+    c = vv_model_cfg()
+    c.n_mel, c.n_fft, c.win_length, c.hop_length = spec.n_mel, spec.n_fft, spec.win_length, spec.hop_length
+    c.dim, c.depth, c.heads, c.head_dim, c.ff_mult = spec.dim, spec.depth, spec.heads, spec.head_dim, spec.ff_mult
+    c.text_dim, c.text_layers, c.text_conv_k, c.text_ff_mult = spec.text_dim, spec.text_layers, spec.text_conv_k, spec.text_ff_mult
+    c.vocab_rows = spec.vocab_size + 1
+    c.pos_conv_k, c.pos_conv_groups, c.time_freq_dim = spec.pos_conv_k, spec.pos_conv_groups, spec.time_freq_dim
+    c.cfg_strength = spec.cfg_strength
+    c.voc_pre_ch, c.voc_pre_k, c.voc_post_k = spec.voc_pre_ch, spec.voc_pre_k, spec.voc_post_k
+    c.voc_n_up = len(spec.voc_up_rates)
+    for i, (r, k) in enumerate(zip(spec.voc_up_rates, spec.voc_up_kernels)):
+        c.voc_up_rates[i], c.voc_up_kernels[i] = r, k
+    c.voc_n_res = len(spec.voc_res_kernels)
+    for i, k in enumerate(spec.voc_res_kernels):
+        c.voc_res_kernels[i] = k
+    c.voc_n_dil = len(spec.voc_res_dilations)
+    for i, d in enumerate(spec.voc_res_dilations):
+        c.voc_res_dilations[i] = d
+    c.voc_lrelu = spec.voc_lrelu
+    c.max_pos = pack.MAX_POS
+    return c
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dt(s) -> Tuple[int, torch.dtype]:
+    if s in ("bf16", "bfloat16", torch.bfloat16, VV_BF16):
+        return VV_BF16, torch.bfloat16
+    if s in ("fp32", "f32", "float32", torch.float32, VV_F32):
+        return VV_F32, torch.float32
+    raise ValueError(f"acoustic dtype must be bf16 or fp32, got {s!r}")
+
+
+class HipSynth:
+    """One GPU's synthesis engine: weights resident in HBM, three device-resident stages.
+
+    flat_weights: optional pre-filled flat uint8 device buffer (e.g. received by RCCL broadcast);
+    otherwise ``weights`` (fp32 CPU dict) is packed and uploaded here.
+    """
+
+    def __init__(self, spec: ModelSpec, weights: Optional[Dict[str, torch.Tensor]] = None, device: str = "cuda:0",
+                 acoustic_dtype="bf16", nfe_step: int = 32, flat_weights: Optional[torch.Tensor] = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise HipUnavailable("no HIP device is visible to torch; the synthesis hot path runs only on the GPU")
+        self.spec = spec
+        self.device = torch.device(device)
+        self.dt_code, self.dt_torch = _dt(acoustic_dtype)
+        self._lock = threading.Lock()        # one stream of calls per context (reference: api/tts_engine.py:64-67)
+        self.ctx = C.c_void_p()
+        cfg = cfg_from_spec(spec)
+        idx = self.device.index if self.device.index is not None else 0
+        rc = self.lib.vv_create(C.byref(self.ctx), idx, C.byref(cfg), self.dt_code)
+        if rc != 0:
+            raise HipUnavailable(f"vv_create failed ({rc}): {self.lib.vv_last_error(None).decode()}")
+        table, total = pack.plan(spec, self.dt_torch)
+        if flat_weights is None:
+            if weights is None:
+                raise ValueError("either weights or flat_weights is required")
+            cpu = torch.zeros(total, dtype=torch.uint8)
+            pack.fill(spec, self.dt_torch, weights, cpu)
+            flat_weights = cpu.to(self.device)
+        assert flat_weights.dtype == torch.uint8 and flat_weights.numel() >= total and flat_weights.is_cuda
+        self.flat = flat_weights
+        base = self.flat.data_ptr()
+        for name, off, nb in table:
+            self._check(self.lib.vv_bind_weight(self.ctx, name.encode(), base + off, nb))
+        self._check(self.lib.vv_finalize_weights(self.ctx))
+        cq, sq, ck, sk = pack.rope_tables(spec)
+        self.rope = tuple(t.to(self.device) for t in (cq, sq, ck, sk))
+        self.nfe_step = None
+        self.set_nfe(nfe_step)
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"vvtts HIP call failed ({rc}): {self.lib.vv_last_error(self.ctx).decode()}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.vv_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_nfe(self, nfe_step: int):
+        if nfe_step == self.nfe_step:
+            return
+        if nfe_step < 2:
+            raise ValueError("nfe_step must be >= 2")
+        t, dt = time_grid(nfe_step, self.spec.sway_coef)
+        sinus = pack.time_sinus_table(self.spec, t).contiguous()
+        dtc = dt.contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vv_set_time_grid(self.ctx, sinus.data_ptr(), dtc.data_ptr(), int(t.numel()), self._stream()))
+        self.nfe_step = nfe_step
+        self.n_steps = int(t.numel())
+
+    # ------------------------------------------------------------------ stages
+    def preprocess(self, audio: torch.Tensor, audio_len: torch.Tensor, text_ids: torch.Tensor, text_len: torch.Tensor,
+                   seq_len: torch.Tensor, N: int, max_audio_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """audio int16 [B,S], text_ids int32 [B,T], *_len int32 [B] -- all on the device."""
+        B = audio.shape[0]
+        for t, d in ((audio, torch.int16), (audio_len, torch.int32), (text_ids, torch.int32), (text_len, torch.int32), (seq_len, torch.int32)):
+            assert t.is_cuda and t.dtype == d and t.is_contiguous(), "preprocess inputs must be contiguous device tensors"
+        s = self.spec
+        cat = torch.empty((B, N, s.cond_dim), dtype=torch.float32, device=self.device)
+        cat_drop = torch.empty_like(cat)
+        ref_len = torch.empty((B,), dtype=torch.int32, device=self.device)
+        mal = int(max_audio_len if max_audio_len is not None else audio.shape[1])
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_preprocess(self.ctx, B, N, audio.data_ptr(), audio.shape[1], mal, audio_len.data_ptr(),
+                                               text_ids.data_ptr(), text_ids.shape[1], text_len.data_ptr(), seq_len.data_ptr(),
+                                               cat.data_ptr(), cat_drop.data_ptr(), ref_len.data_ptr(), self._stream()))
+        return {"cat_mel_text": cat, "cat_mel_text_drop": cat_drop, "ref_signal_len": ref_len, "seq_len": seq_len,
+                "rope_cos_q": self.rope[0][:N], "rope_sin_q": self.rope[1][:N], "rope_cos_k": self.rope[2][:N],
+                "rope_sin_k": self.rope[3][:N]}
+
+    def transformer_steps(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], step0: int, n_steps: int) -> torch.Tensor:
+        """x fp32 [B,N,n_mel] updated in place on the device."""
+        B, N, M = x.shape
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and M == self.spec.n_mel
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_transformer_steps(self.ctx, B, N, pre["seq_len"].data_ptr(), x.data_ptr(),
+                                                      pre["cat_mel_text"].data_ptr(), pre["cat_mel_text_drop"].data_ptr(),
+                                                      pre["rope_cos_q"].data_ptr(), pre["rope_sin_q"].data_ptr(),
+                                                      pre["rope_cos_k"].data_ptr(), pre["rope_sin_k"].data_ptr(),
+                                                      step0, n_steps, self._stream()))
+        return x
+
+    def decode(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], t_gen_max: int, want_wave: bool = False):
+        B, N, _ = x.shape
+        hop = self.spec.hop_length
+        pcm = torch.zeros((B, t_gen_max * hop), dtype=torch.int16, device=self.device)
+        pcm_len = torch.empty((B,), dtype=torch.int32, device=self.device)
+        wave = torch.zeros((B, t_gen_max * hop), dtype=torch.float32, device=self.device) if want_wave else None
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_decode(self.ctx, B, N, x.data_ptr(), pre["ref_signal_len"].data_ptr(), pre["seq_len"].data_ptr(),
+                                           t_gen_max, pcm.data_ptr(), pcm.shape[1], pcm_len.data_ptr(), _ptr(wave), self._stream()))
+        return (pcm, pcm_len, wave) if want_wave else (pcm, pcm_len)
+
+    def synthesize_batch(self, audio, audio_len, text_ids, text_len, seq_len, N: int, noise: torch.Tensor, t_gen_max: int,
+                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None):
+        """Whole hot path for a batch, state resident in HBM: preprocess -> ODE steps -> vocoder."""
+        pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len)
+        x = noise.clone()
+        self.transformer_steps(x, pre, 0, self.n_steps if n_steps is None else n_steps)
+        pcm, pcm_len = self.decode(x, pre, t_gen_max)
+        return x, pcm, pcm_len, pre
+
+    # ------------------------------------------------------------------ profiling
+    def prof_enable(self, on: bool):
+        self._check(self.lib.vv_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_collect(self) -> Dict[str, Dict[str, float]]:
+        n = len(PROF_CLASSES)
+        la, ms, fl, by = (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        self._check(self.lib.vv_prof_collect(self.ctx, la, ms, fl, by))
+        return {PROF_CLASSES[i]: {"launches": int(la[i]), "ms": float(ms[i]), "flops": float(fl[i]), "bytes": float(by[i])}
+                for i in range(n)}
