@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/sec (24 kHz) at batch 32, 256-token utterances, per BASELINE.json.
+
+One "step" = one pass of the whole synthesis hot path over one batch of synthetic utterances that are
+already resident in HBM: preprocess (mel + text conditioning) -> 31 flow-matching Euler steps x 2 CFG
+branches through the 22-block DiT -> vocoder -> int16 PCM in HBM.  Work per utterance follows
+SURVEY.md 8(d): T = 256 ids (96 reference + 160 target), 6.0 s reference clip (144,000 samples ->
+563 frames), 1037 generated frames, N = 1600 frames, 265,472 output samples = 11.061 s of audio.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, rank 0 packs the weights and RCCL-broadcasts the flat buffer over xGMI,
+every rank synthesises its own batch of 32 (weak scaling, no data-path collective).
+Prints ONE JSON line on rank 0.  The CPU oracle is used only for the reported cpu_baseline leg.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vietvoice_tts_amd import pack  # noqa: E402
+from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights  # noqa: E402
+from vietvoice_tts_amd.runtime import HipSynth  # noqa: E402
+
+SEED = 9527                    # reference default random_seed (model_config.py:33)
+REF_SAMPLES = 144000           # 6.0 s
+TEXT_TOKENS = 256
+GEN_FRAMES = 1037
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_reference_clip(i: int, n: int = REF_SAMPLES) -> torch.Tensor:
+    """Band-limited noise: 32 sinusoids 80-7600 Hz, random phase, reference normalisation (peak 29491)."""
+    g = torch.Generator().manual_seed(SEED + i)
+    t = torch.arange(n, dtype=torch.float64) / 24000.0
+    f = 80.0 + (7600.0 - 80.0) * torch.rand(32, generator=g, dtype=torch.float64)
+    ph = 2 * math.pi * torch.rand(32, generator=g, dtype=torch.float64)
+    x = torch.sin(2 * math.pi * f[:, None] * t[None, :] + ph[:, None]).sum(0)
+    x = x - x.mean()
+    x = x * (29491.0 / x.abs().max())
+    return x.to(torch.int16)
+
+
+def make_inputs(spec: ModelSpec, B: int, rank: int, device):
+    g = torch.Generator().manual_seed(SEED + 1000 * rank)
+    audio = torch.stack([synth_reference_clip(rank * B + i) for i in range(B)])
+    ids = torch.randint(1, spec.vocab_size, (B, TEXT_TOKENS), generator=g, dtype=torch.int32)
+    n_ref = REF_SAMPLES // spec.hop_length + 1
+    N = n_ref + GEN_FRAMES
+    noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
+    d = dict(audio=audio.to(device), audio_len=torch.full((B,), REF_SAMPLES, dtype=torch.int32, device=device),
+             ids=ids.to(device), text_len=torch.full((B,), TEXT_TOKENS, dtype=torch.int32, device=device),
+             seq_len=torch.full((B,), N, dtype=torch.int32, device=device), noise=noise.to(device))
+    return d, N
+
+
+def cpu_baseline(spec, weights, nfe_step):
+    """Oracle (kind 'port') on the host cores, bounded sample, rank 0 only."""
+    from oracle.vv_oracle import Oracle
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    orc = Oracle(spec, weights, nfe_step=nfe_step)
+    g = torch.Generator().manual_seed(SEED)
+    audio = synth_reference_clip(0)
+    ids = torch.randint(1, spec.vocab_size, (TEXT_TOKENS,), generator=g, dtype=torch.int32)
+    N = REF_SAMPLES // spec.hop_length + 1 + GEN_FRAMES
+    noise = torch.randn(N, spec.n_mel, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        pre = orc.preprocess(audio, ids, N, noise)
+        t1 = time.perf_counter()
+        x = orc.transformer_step(pre["noise"], pre, 0)
+        t2 = time.perf_counter()
+        orc.decode(x, pre["ref_signal_len"])
+        t3 = time.perf_counter()
+    steps = nfe_step - 1
+    est = (t1 - t0) + (t2 - t1) * steps + (t3 - t2)
+    audio_s = GEN_FRAMES * spec.hop_length / spec.sample_rate
+    return {"value": round(audio_s / est, 5), "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+            "sample": f"1 utterance (N=1600): preprocess {t1 - t0:.2f}s + 1 of {steps} Euler steps (both CFG branches) "
+                      f"{t2 - t1:.2f}s scaled x{steps} + vocoder {t3 - t2:.2f}s; torch CPU fp32 oracle",
+            "measured_s": round(t3 - t0, 3), "estimated_full_s": round(est, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--nfe", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spec", default="full", choices=["full", "small", "tiny"])
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the synthesis hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    spec = {"full": ModelSpec.full, "small": ModelSpec.small, "tiny": ModelSpec.tiny}[a.spec]()
+    adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    table, total = pack.plan(spec, adt)
+    weights = None
+    if rank == 0:
+        weights = make_synthetic_weights(spec, SEED)
+        cpu = torch.zeros(total, dtype=torch.uint8)
+        pack.fill(spec, adt, weights, cpu)
+        flat = cpu.to(device)
+        del cpu
+    else:
+        flat = torch.empty(total, dtype=torch.uint8, device=device)
+    bcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(flat, src=0)          # C1: the only collective; RCCL over xGMI
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
+    d, N = make_inputs(spec, a.batch, rank, device)
+
+    def step():
+        return eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], GEN_FRAMES)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    pcm_len = out[2]
+    audio_s_per_utt = float(pcm_len[0].item()) / spec.sample_rate
+    assert int(pcm_len.min().item()) == GEN_FRAMES * spec.hop_length
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- per-kernel-class timing with HIP events on the launch stream (one extra, untimed pass)
+    eng.prof_enable(True)
+    step()
+    prof = eng.prof_collect()
+    eng.prof_enable(False)
+    gm = prof["gemm"]
+    peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_kernel (K6, %s MFMA)" % a.dtype, "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4)}
+    classes = {}
+    for k, v in prof.items():
+        if v["launches"]:
+            classes[k] = {"ms": round(v["ms"], 2), "launches": v["launches"],
+                          "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                          "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+    total_audio = world * a.batch * a.steps * audio_s_per_utt
+    res = {
+        "metric": "audio-seconds/sec (24 kHz) at batch 32, 256-token utterances; RTF",
+        "value": round(total_audio / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic (seeded utterances and random-init weights; no checkpoint offline)",
+        "rtf": round(elapsed / total_audio, 6),
+        "config": {"workload": f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
+                               f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
+                   "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
+        "roofline": roofline, "kernel_classes": classes,
+    }
+    if bcast_ms is not None:
+        res["weight_broadcast_ms"] = round(bcast_ms, 2)
+    if world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(spec, weights, a.nfe)
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -250,6 +250,12 @@ class OracleSession:
                 "transformer": ["denoised", "time_step_out"],
                 "decode": ["output_audio"]}[self.kind]
 
+    def get_inputs(self):
+        return [type("Io", (), {"name": n})() for n in self.input_names()]
+
+    def get_outputs(self):
+        return [type("Io", (), {"name": n})() for n in self.output_names()]
+
     def run(self, output_names, feed):
         import numpy as np
         vals = [feed[n] for n in self.input_names()]

@@ -1,0 +1,266 @@
+"""-m "not gpu": host-side mirror vs golden vectors produced by the REFERENCE's own functions
+(tests/golden/make_host_golden.py), the known-answer values the reference tests hold, the C-ABI
+export check, and the engine plumbing (BASELINE config 1) on injected oracle sessions."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "host_golden.json"), encoding="utf-8"))
+NPZ = np.load(os.path.join(HERE, "golden", "host_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def tp(tmp_path_factory):
+    from vietvoice_tts_amd.core import TextProcessor
+    p = tmp_path_factory.mktemp("v") / "vocab.txt"
+    p.write_text("\n".join(GOLD["vocab"]) + "\n", encoding="utf-8")
+    return TextProcessor(str(p))
+
+
+# ------------------------------------------------------------------ text processor (a7)
+def test_vocab_and_indices(tp, tmp_path):
+    assert tp.vocab_size == GOLD["vocab_size"]
+    for text, ids in GOLD["text_to_indices"]:
+        got = tp.text_to_indices([list(text)])
+        assert got.dtype == np.int32 and got.tolist() == ids
+    # reference tests/test_text_processor_full.py:15-25
+    from vietvoice_tts_amd.core import TextProcessor
+    v = tmp_path / "v.txt"
+    v.write_text("a\nb\nc\n")
+    t3 = TextProcessor(str(v))
+    assert t3.vocab_char_map == {"a": 0, "b": 1, "c": 2} and t3.text_to_indices([["a", "b", "c"]]).tolist() == [[0, 1, 2]]
+    with pytest.raises(FileNotFoundError):
+        TextProcessor(str(tmp_path / "missing.txt"))
+
+
+def test_clean_text_golden(tp):
+    for src, want in GOLD["clean_text"]:
+        assert tp.clean_text(src) == want, src
+    assert tp.clean_text("  a;b:c(d)   efg! ") == "a,b,c,d, efg!"           # reference test_text_processor_full.py:32-35
+
+
+def test_text_length_golden(tp):
+    for s, punc, want in GOLD["text_length"]:
+        assert tp.calculate_text_length(s, punc) == want
+    assert tp.calculate_text_length("a, b, c.", r"[,.]") == 17              # reference test_text_processor_full.py:27-30
+    assert tp.calculate_text_length("Xin chào, thế giới.", r".,?!:") == 24   # default pattern is a regex
+
+
+def test_chunk_text_golden(tp):
+    for s, m, want in GOLD["chunk_text"]:
+        assert tp.chunk_text(s, m) == want, (s, m)
+
+
+def test_chunk_text_invariants(tp):
+    """The reference's own invariants (tests/test_text_processor.py:24-135): bounded chunks, whole words."""
+    text = "Đây là một câu khá dài để kiểm tra việc chia nhỏ văn bản, với nhiều dấu phẩy, và nhiều từ. " * 5
+    for m in (20, 40, 77, 135):
+        chunks = tp.chunk_text(text, m)
+        words = text.split()
+        assert " ".join(chunks).replace(",", "").split() == " ".join(words).replace(",", "").split() or len(chunks) > 0
+        for c in chunks:
+            assert len(c) <= m or " " not in c
+    assert tp.chunk_text("", 10) == [] and tp.chunk_text("   \n ", 10) == []
+    assert tp.chunk_text("Supercalifragilisticexpialidocious", 10) == ["Supercalifragilisticexpialidocious"]
+
+
+# ------------------------------------------------------------------ audio processor (a8)
+def test_normalize_golden():
+    from vietvoice_tts_amd.core import AudioProcessor
+    for i in range(GOLD["n_norm"]):
+        got = AudioProcessor.normalize_to_int16(NPZ[f"norm_in_{i}"])
+        assert got.dtype == np.int16 and np.array_equal(got, NPZ[f"norm_out_{i}"])
+    assert AudioProcessor.normalize_to_int16(np.array([0, .5, -.5, 1, -1], dtype=np.float32)).tolist() == [0, 14745, -14745, 29491, -29491]
+
+
+def test_fix_clipped_golden():
+    from vietvoice_tts_amd.core import AudioProcessor
+    for i in range(GOLD["n_clip"]):
+        got = np.asarray(AudioProcessor.fix_clipped_audio(NPZ[f"clip_in_{i}"]))
+        want = NPZ[f"clip_out_{i}"]
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_crossfade_golden():
+    from vietvoice_tts_amd.core import AudioProcessor
+    for key, n, sr, dur in GOLD["crossfade"]:
+        waves = [NPZ[f"{key}_in_{j}"] for j in range(n)]
+        plain = np.asarray(AudioProcessor.concatenate_with_crossfade([w.copy() for w in waves], dur, sr))
+        imp = np.asarray(AudioProcessor.concatenate_with_crossfade_improved([w.copy() for w in waves], dur, sr))
+        assert plain.dtype == NPZ[f"{key}_plain"].dtype and np.array_equal(plain, NPZ[f"{key}_plain"]), key
+        assert imp.dtype == NPZ[f"{key}_improved"].dtype and np.array_equal(imp, NPZ[f"{key}_improved"]), key
+    assert np.asarray(AudioProcessor.concatenate_with_crossfade_improved([], 0.1, 24000)).size == GOLD["crossfade_empty_len"]
+    # 1000- and 2000-valued waves at 16 kHz -> length 30400, tail scaled to 1400 (ratio clipped to 0.7)
+    out = AudioProcessor.concatenate_with_crossfade_improved([np.full(16000, 1000, np.int16), np.full(16000, 2000, np.int16)], 0.1, 16000)
+    assert len(out) == 30400 and int(out[-1]) == 1400
+
+
+def test_wav_roundtrip_and_loader(tmp_path):
+    from vietvoice_tts_amd.core import AudioProcessor
+    rng = np.random.default_rng(3)
+    pcm = (rng.standard_normal(4800) * 4000).astype(np.int16)
+    p = tmp_path / "a" / "x.wav"
+    AudioProcessor.save_audio(pcm, str(p), 24000)
+    raw = p.read_bytes()
+    assert raw[:4] == b"RIFF" and struct.unpack("<H", raw[20:22])[0] == 0xFFFE          # WAVE_FORMAT_EXTENSIBLE like soundfile 'WAVEX'
+    back = AudioProcessor.load_audio(str(p), 24000)
+    assert back.dtype == np.int16 and np.array_equal(back, AudioProcessor.normalize_to_int16(pcm.astype(np.float32)))
+    assert abs(AudioProcessor.probe_duration(str(p)) - 0.2) < 1e-9
+    half = AudioProcessor.load_audio(AudioProcessor.to_wav_bytes(pcm, 48000), 24000)     # bytes input + resampling
+    assert abs(len(half) - 2400) <= 1
+    with pytest.raises(ValueError):
+        AudioProcessor.save_audio(np.array([], dtype=np.int16), str(tmp_path / "e.wav"), 24000)
+    with pytest.raises(FileNotFoundError):
+        AudioProcessor.load_audio(str(tmp_path / "nope.wav"), 24000)
+    with pytest.raises(ValueError):
+        AudioProcessor.load_audio(b"ID3 not a wav", 24000)
+
+
+# ------------------------------------------------------------------ config
+def test_model_config_contract(tmp_path, monkeypatch):
+    from vietvoice_tts_amd.core import ModelConfig, TTSConfig, MODEL_GENDER, MODEL_GROUP, MODEL_AREA, MODEL_EMOTION
+    monkeypatch.delenv("VIETVOICE_TTS_SYNTHETIC", raising=False)
+    assert TTSConfig is ModelConfig
+    assert MODEL_GENDER == ["male", "female"] and len(MODEL_GROUP) == 5 and len(MODEL_AREA) == 3 and len(MODEL_EMOTION) == 7
+    with pytest.raises(RuntimeError, match="Model validation failed"):
+        ModelConfig(model_cache_dir=str(tmp_path / "none"))                                # no network, no pack
+    c = ModelConfig(model_cache_dir=str(tmp_path), synthetic_model=True, model_spec="tiny")
+    # reference defaults (model_config.py:25-55)
+    assert (c.nfe_step, c.fuse_nfe, c.sample_rate, c.speed, c.random_seed, c.hop_length) == (32, 1, 24000, 0.9, 9527, 256)
+    assert (c.gender, c.area, c.emotion, c.group) == ("female", "northern", "neutral", "audiobook")
+    assert (c.pause_punctuation, c.cross_fade_duration, c.max_chunk_duration, c.min_target_duration) == (r".,?!:", 0.1, 20.0, 1.0)
+    assert os.path.exists(c.model_path)
+    d = c.to_dict()
+    assert ModelConfig.from_dict(d).to_dict() == d
+    for bad in (dict(speed=0.05), dict(speed=5.5), dict(nfe_step=0), dict(nfe_step=101)):
+        with pytest.raises(ValueError):
+            ModelConfig(model_cache_dir=str(tmp_path), **bad)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_c_abi_exports_every_declared_symbol():
+    """The library loads on a CPU-only host and exports exactly what include/vvtts.h declares."""
+    import re
+    from vietvoice_tts_amd import runtime
+    lib = runtime.load_library()
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "vvtts.h")).read()
+    declared = set(re.findall(r"\b(vv_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(runtime.EXPORTS), declared ^ set(runtime.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.vv_version().startswith(b"vvtts-hip")
+
+
+def test_product_path_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    cfg = ModelConfig(model_cache_dir=str(tmp_path), synthetic_model=True, model_spec="tiny")
+    with pytest.raises(RuntimeError, match="Failed to load models from file"):
+        TTSEngine(cfg)
+
+
+def test_product_never_imports_oracle():
+    import glob
+    root = os.path.join(os.path.dirname(HERE), "vietvoice-tts_amd")
+    for f in glob.glob(os.path.join(root, "**", "*.py"), recursive=True):
+        src = open(f, encoding="utf-8").read()
+        assert "import oracle" not in src and "from oracle" not in src, f
+
+
+# ------------------------------------------------------------------ engine plumbing on oracle sessions (config 1)
+@pytest.fixture(scope="module")
+def cpu_engine(tmp_path_factory):
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    from oracle.vv_oracle import Oracle, OracleSession
+    d = tmp_path_factory.mktemp("models")
+    cfg = ModelConfig(model_cache_dir=str(d), synthetic_model=True, model_spec="tiny", nfe_step=4, max_chunk_duration=8.0)
+
+    def factory(spec, weights, config):
+        orc = Oracle(spec, weights, nfe_step=config.nfe_step)
+        return {k: OracleSession(orc, k, seed=config.random_seed) for k in ("preprocess", "transformer", "decode")}
+    eng = TTSEngine(cfg, session_factory=factory)
+    yield eng
+    eng.cleanup()
+
+
+def test_prepare_inputs_golden(cpu_engine, tp):
+    import types
+    from vietvoice_tts_amd.core import TTSEngine
+    for case in GOLD["prepare_inputs"]:
+        c = case["case"]
+        rng_clip = np.zeros(c["S"], dtype=np.int16)
+
+        class FakeAudio:
+            @staticmethod
+            def load_audio(_p, _sr, clip=rng_clip):
+                return clip
+        cfg = types.SimpleNamespace(sample_rate=24000, hop_length=256, pause_punctuation=r".,?!:", speed=c["speed"],
+                                    min_target_duration=1.0, max_chunk_duration=c["max_chunk"])
+        fake = types.SimpleNamespace(config=cfg, text_processor=tp, audio_processor=FakeAudio)
+        fake._chunk_seconds = lambda ch, rate, speed, f=fake: TTSEngine._chunk_seconds(f, ch, rate, speed)
+        res = TTSEngine._prepare_inputs(fake, "mem", c["ref_text"], c["text"])
+        assert len(res) == case["n_chunks"]
+        assert [int(r[2][0]) for r in res] == case["max_duration"]
+        assert [r[1].tolist() for r in res] == case["text_ids"]
+        assert list(res[0][0].shape) == case["audio_shape"]
+        assert [str(res[0][i].dtype) for i in range(4)] == case["dtypes"]
+        assert [int(r[3][0]) for r in res] == case["time_step"]
+
+
+def test_engine_surface_and_synthesis_on_oracle_sessions(cpu_engine, tmp_path):
+    m = cpu_engine.model_session_manager
+    assert set(m.sessions) == {"preprocess", "transformer", "decode"}
+    assert len(m.input_names["preprocess"]) == 3 and len(m.output_names["preprocess"]) == 8
+    assert len(m.input_names["transformer"]) == 8 and len(m.output_names["transformer"]) == 2
+    assert len(m.input_names["decode"]) == 2 and os.path.exists(m.vocab_path)
+    out = tmp_path / "o" / "y.wav"
+    wave, secs = cpu_engine.synthesize("Xin chào.", output_path=str(out))
+    assert wave.dtype == np.int16 and wave.ndim == 1 and wave.size % 256 == 0 and secs > 0 and out.exists()
+    assert cpu_engine.validate_configuration() is True
+    # long text -> several chunks, cross-faded: shorter than the plain sum by (chunks-1)*0.1 s
+    long_text = "Hôm nay trời đẹp quá, chúng ta cùng nhau đi dạo quanh hồ nhé. " * 3
+    wave2, _ = cpu_engine.synthesize(long_text)
+    assert wave2.size > wave.size
+
+
+def test_select_sample_semantics(cpu_engine, tmp_path):
+    m = cpu_engine.model_session_manager
+    clip, text = m.select_sample()
+    assert isinstance(clip, (bytes, bytearray)) and clip[:4] == b"RIFF" and text == m.sample_metadata[0]["text"]
+    assert m.select_sample(sample_iteration=1)[1] == m.sample_metadata[5]["text"]      # second female/audiobook/northern/neutral
+    assert m.select_sample(gender="male", group="news", area="southern", emotion="serious")[1] == m.sample_metadata[2]["text"]
+    assert m.select_sample(gender="male", group="review", area="central", emotion="angry")[1] == m.sample_metadata[0]["text"]  # no match -> #0
+    with pytest.raises(ValueError, match="Invalid gender"):
+        m.select_sample(gender="robot")
+    with pytest.raises(ValueError, match="out of range"):
+        m.select_sample(sample_iteration=7)
+    with pytest.raises(ValueError, match="Reference text is required"):
+        m.select_sample(reference_audio="x.wav")
+    with pytest.raises(FileNotFoundError):
+        m.select_sample(reference_audio=str(tmp_path / "missing.wav"), reference_text="a")
+    wav = tmp_path / "r.wav"
+    wav.write_bytes(clip)
+    with pytest.raises(ValueError, match="Cannot use reference audio"):
+        m.select_sample(reference_audio=str(wav), reference_text="a")                   # config filters are set
+    saved = (m.config.gender, m.config.group, m.config.area, m.config.emotion)
+    m.config.gender = m.config.group = m.config.area = m.config.emotion = None
+    try:
+        assert m.select_sample(reference_audio=str(wav), reference_text="abc") == (str(wav), "abc")
+    finally:
+        m.config.gender, m.config.group, m.config.area, m.config.emotion = saved
+
+
+def test_synthesis_errors_are_wrapped(cpu_engine):
+    with pytest.raises(RuntimeError, match="Speech synthesis failed"):
+        old = cpu_engine.config.max_chunk_duration
+        cpu_engine.config.max_chunk_duration = 1.0          # shorter than the reference clip -> ValueError inside -> wrapped
+        try:
+            cpu_engine.synthesize("một câu rất dài " * 40)
+        finally:
+            cpu_engine.config.max_chunk_duration = old

@@ -343,7 +343,12 @@ def test_mel_frontend(hip_tiny, tiny_setup):
         ref = orc.mel(audio[i, :L])
         got = mel[i, : ref.shape[0]].cpu()
         assert ref.shape[0] == L // 256 + 1
-        assert float((got - ref).abs().max()) < 2e-3, float((got - ref).abs().max())     # log domain, abs
+        # linear-domain check (1e-4 of the frame peak) + log-domain check where the bin is not ~silent:
+        # log() of a near-zero bin amplifies the fp32 DFT-vs-FFT rounding difference without bound
+        lin_g, lin_r = got.exp(), ref.exp()
+        assert float((lin_g - lin_r).abs().max()) < 1e-4 * float(lin_r.max()), float((lin_g - lin_r).abs().max())
+        loud = lin_r > 1e-3 * lin_r.max()
+        assert float((got - ref)[loud].abs().max()) < 2e-3, float((got - ref)[loud].abs().max())
         if i == 0:   # known answer: a 440 Hz tone peaks in the mel bin whose centre is nearest 440 Hz
             peak = int(ref[10].argmax())
             assert int(got[10].argmax()) == peak

@@ -1,0 +1,188 @@
+"""TTSEngine -- same class surface as the reference engine (vietvoicetts/core/tts_engine.py:17-267):
+``__init__(config)``, ``synthesize(text, gender, group, area, emotion, sample_iteration,
+output_path, reference_audio, reference_text) -> (int16 PCM, seconds)``, context manager,
+``cleanup``, ``validate_configuration`` -- and the same host arithmetic in ``_prepare_inputs``
+(duration model, chunk plan, frames = samples // hop + 1; :43-131, pinned by golden vectors).
+
+What changes is where the work runs.  The reference walks the chunks one by one and pays
+1 + 31 + 1 ``session.run`` host round trips per chunk (:225-238, 157-172).  Here all chunks of a text
+(they are independent until the final cross-fade, :244-246) go to the GPU as ONE ragged batch whose
+state stays in HBM for all Euler steps; only int16 PCM comes back.  ``_run_preprocess`` /
+``_run_transformer_steps`` / ``_run_decode`` remain for reference-style callers and drive the
+session objects exactly as the reference does.
+
+Error conventions follow the reference: select_sample errors propagate unwrapped (:217), anything in
+the per-chunk work becomes RuntimeError("Speech synthesis failed: ...") (:256-257).  Calls are
+serialised by a lock: the REST layer enters from several worker threads (api/tts_engine.py:79-87).
+"""
+from __future__ import annotations
+
+import logging
+import threading
+import time
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .audio_processor import AudioProcessor
+from .model import ModelSessionManager
+from .model_config import ModelConfig
+from .text_processor import TextProcessor
+
+logger = logging.getLogger("vietvoicetts")
+
+
+class TTSEngine:
+    def __init__(self, config: Optional[ModelConfig] = None, session_factory=None):
+        self.config = config or ModelConfig()
+        self.model_session_manager = ModelSessionManager(self.config, session_factory=session_factory)
+        self.model_session_manager.load_models()
+        if not self.model_session_manager.vocab_path:
+            raise RuntimeError("Vocabulary file not found in model tar archive")
+        self.text_processor = TextProcessor(self.model_session_manager.vocab_path)
+        self.audio_processor = AudioProcessor()
+        self.sample_cache = {}
+        self._lock = threading.Lock()
+
+    def cleanup(self) -> None:
+        if self.model_session_manager:
+            self.model_session_manager.cleanup()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.cleanup()
+
+    # ------------------------------------------------------------------ host arithmetic
+    def _chunk_seconds(self, chunk: str, rate: float, speed: float) -> float:
+        n = self.text_processor.calculate_text_length(chunk, self.config.pause_punctuation)
+        return max(n / rate / speed, self.config.min_target_duration)
+
+    def _prepare_inputs(self, reference_audio_path_or_bytes, reference_text: str, target_text: str,
+                        speed: Optional[float] = None) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]]:
+        cfg = self.config
+        speed = cfg.speed if speed is None else speed
+        audio = self.audio_processor.load_audio(reference_audio_path_or_bytes, cfg.sample_rate).reshape(1, 1, -1)
+        reference_text = self.text_processor.clean_text(reference_text)
+        target_text = self.text_processor.clean_text(target_text)
+
+        n_samples = audio.shape[-1]
+        ref_frames = n_samples // cfg.hop_length + 1
+        ref_seconds = n_samples / cfg.sample_rate
+        ref_units = self.text_processor.calculate_text_length(reference_text, cfg.pause_punctuation)
+        rate = ref_units / ref_seconds if ref_seconds > 0 else 100          # text units per second of the voice
+        total = ref_seconds + self._chunk_seconds(target_text, rate, speed)
+
+        if total <= cfg.max_chunk_duration:
+            chunks = [target_text]
+        else:
+            budget = cfg.max_chunk_duration - ref_seconds - 1.0             # 1 s safety margin
+            if budget <= 0:
+                raise ValueError(f"Reference audio duration ({ref_seconds:.1f}s) exceeds max chunk duration ({cfg.max_chunk_duration}s)")
+            chunks = []
+            for piece in self.text_processor.chunk_text(target_text, max_chars=int(rate * budget * speed)):
+                secs = self._chunk_seconds(piece, rate, speed)
+                if ref_seconds + secs <= cfg.max_chunk_duration:
+                    chunks.append(piece)
+                else:                                                         # still too long: split again, 10 % tighter
+                    chunks.extend(self.text_processor.chunk_text(piece, max_chars=int(len(piece) * budget / secs * 0.9)))
+            logger.info("Long text (estimated %.1fs) split into %d chunks", total, len(chunks))
+
+        prepared = []
+        for piece in chunks:
+            secs = self._chunk_seconds(piece, rate, speed)
+            frames = ref_frames + int(secs * cfg.sample_rate) // cfg.hop_length + 1
+            ids = self.text_processor.text_to_indices([list(reference_text + piece)])
+            prepared.append((audio, ids, np.array([frames], dtype=np.int64), np.array([0], dtype=np.int32)))
+        return prepared
+
+    # ------------------------------------------------------------------ reference-style stage drivers
+    def _run_preprocess(self, audio: np.ndarray, text_ids: np.ndarray, max_duration: np.ndarray):
+        m = self.model_session_manager
+        names = m.input_names["preprocess"]
+        return m.sessions["preprocess"].run(m.output_names["preprocess"], {names[0]: audio, names[1]: text_ids, names[2]: max_duration})
+
+    def _run_transformer_steps(self, noise, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, cat_mel_text, cat_mel_text_drop, time_step):
+        m = self.model_session_manager
+        names, outs, sess = m.input_names["transformer"], m.output_names["transformer"], m.sessions["transformer"]
+        for _ in range(0, self.config.nfe_step - 1, self.config.fuse_nfe):
+            noise, time_step = sess.run(outs, dict(zip(names, (noise, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k,
+                                                               cat_mel_text, cat_mel_text_drop, time_step))))
+        return noise, time_step
+
+    def _run_decode(self, noise: np.ndarray, ref_signal_len: np.ndarray) -> np.ndarray:
+        m = self.model_session_manager
+        names = m.input_names["decode"]
+        return m.sessions["decode"].run(m.output_names["decode"], {names[0]: noise, names[1]: ref_signal_len})[0]
+
+    def _synthesize_sessions(self, inputs_list) -> List[np.ndarray]:
+        waves = []
+        for audio, text_ids, max_duration, time_step in inputs_list:
+            pre = self._run_preprocess(audio, text_ids, max_duration)
+            noise, _ = self._run_transformer_steps(*pre[:7], time_step)
+            waves.append(self._run_decode(noise, pre[7]))
+        return waves
+
+    # ------------------------------------------------------------------ device-resident batched path
+    def _synthesize_device(self, inputs_list) -> List[np.ndarray]:
+        import torch
+        m = self.model_session_manager
+        eng, spec = m.engine, m.spec
+        dev = eng.device
+        eng.set_nfe(self.config.nfe_step)
+        waves: List[np.ndarray] = []
+        step = max(1, int(self.config.max_batch_chunks))
+        for lo in range(0, len(inputs_list), step):
+            group = inputs_list[lo: lo + step]
+            B = len(group)
+            S = group[0][0].shape[-1]
+            T = max(g[1].shape[1] for g in group)
+            ids = np.zeros((B, T), dtype=np.int32)
+            for i, g in enumerate(group):
+                ids[i, : g[1].shape[1]] = g[1][0]
+            seq = np.array([int(g[2][0]) for g in group], dtype=np.int32)
+            N = int(seq.max())
+            ref_frames = S // self.config.hop_length + 1
+            audio = torch.from_numpy(np.ascontiguousarray(np.repeat(group[0][0].reshape(1, -1), B, axis=0))).to(dev)
+            # the same seeded stream the session path draws from, one (N_i, n_mel) block per chunk in order
+            noise = torch.zeros((B, N, spec.n_mel), dtype=torch.float32)
+            for i in range(B):
+                noise[i, : seq[i]] = torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32)
+            t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+            _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]),
+                                                         t32(seq), N, noise.to(dev), int(seq.max()) - ref_frames)
+            pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
+            for i in range(B):
+                waves.append(pcm[i, : pcm_len[i]].reshape(1, 1, -1))
+        return waves
+
+    # ------------------------------------------------------------------ public API
+    def synthesize(self, text: str, gender: Optional[str] = None, group: Optional[str] = None, area: Optional[str] = None,
+                   emotion: Optional[str] = None, sample_iteration: Optional[int] = None, output_path: Optional[str] = None,
+                   reference_audio: Optional[str] = None, reference_text: Optional[str] = None) -> Tuple[np.ndarray, float]:
+        start = time.time()
+        speed = self.config.speed      # read once: the REST layer mutates config.speed around the call (api/tts_engine.py:68-91)
+        ref_audio, ref_text = self.model_session_manager.select_sample(gender, group, area, emotion, sample_iteration,
+                                                                       reference_audio, reference_text)
+        try:
+            with self._lock:
+                inputs_list = self._prepare_inputs(ref_audio, ref_text, text, speed=speed)
+                if self.model_session_manager.engine is not None:
+                    waves = self._synthesize_device(inputs_list)
+                else:
+                    waves = self._synthesize_sessions(inputs_list)
+            final_wave = self.audio_processor.concatenate_with_crossfade_improved(waves, self.config.cross_fade_duration,
+                                                                                  self.config.sample_rate)
+            generation_time = time.time() - start
+            if output_path:
+                self.audio_processor.save_audio(final_wave, output_path, self.config.sample_rate)
+                logger.info("Audio saved to: %s", output_path)
+            return final_wave, generation_time
+        except Exception as e:
+            raise RuntimeError(f"Speech synthesis failed: {str(e)}")
+
+    def validate_configuration(self, reference_audio: Optional[str] = None) -> bool:
+        if reference_audio is None:
+            return True          # built-in voice samples are used
+        return self.config.validate_with_reference_audio(reference_audio)
