@@ -67,7 +67,11 @@ def make_inputs(spec: ModelSpec, B: int, rank: int, device):
 def cpu_baseline(spec, weights, nfe_step):
     """Oracle (kind 'port') on the host cores, bounded sample, rank 0 only."""
     from oracle.vv_oracle import Oracle
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))        # the GPU box grants a 16-core CPU share per GPU; more threads only thrash
     torch.set_num_threads(threads)
     orc = Oracle(spec, weights, nfe_step=nfe_step)
     g = torch.Generator().manual_seed(SEED)

@@ -118,6 +118,7 @@ typedef struct vv_gemm_args {
     int32_t M, N, K;
     const float *bias, *gate, *cos_q, *sin_q, *cos_k, *sin_k;
     int32_t n_store, seq_n, rope_dim;
+    int32_t tile;   /* 0 = auto (256x256 tile when M >= 4096 and N % 256 == 0), 128 or 256 to force */
 } vv_gemm_args;
 int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 

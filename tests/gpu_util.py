@@ -21,7 +21,7 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
 
 
-def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0):
+def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0, tile=0):
     """A [M,K], W [N,K] on device, same dtype (bf16 or f32)."""
     dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
     od = dt if out_dtype is None else out_dtype
@@ -37,7 +37,7 @@ def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=No
     a.gate = None if gate is None else gate.data_ptr()
     if ropes is not None:
         a.cos_q, a.sin_q, a.cos_k, a.sin_k = [t.data_ptr() for t in ropes]
-    a.n_store, a.seq_n, a.rope_dim = n_store, seq_n, rope_dim
+    a.n_store, a.seq_n, a.rope_dim, a.tile = n_store, seq_n, rope_dim, tile
     check(eng, eng.lib.vv_gemm(eng.ctx, C.byref(a), stream()))
     torch.cuda.synchronize()
     return C_io

@@ -102,6 +102,27 @@ def test_gemm_qkv_rope(hip_tiny, dtype, tiny_setup):
     assert gu.rel_err(got, ref) < _tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 192), (256, 256, 64), (5000, 256, 128)])
+def test_gemm_big_tile(hip_tiny, dtype, M, N, K):
+    """The 256x256 / 8-wave variant (auto-selected for M >= 4096) on forced and ragged shapes, all epilogues."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b, gate = torch.randn(N, generator=g) * 0.1, torch.randn(N, generator=g)
+    y = A.float() @ W.float().t() + b
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), act=1, tile=256)
+    assert gu.rel_err(got, F.gelu(y, approximate="tanh")) < _tol(dtype)
+    small = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), act=1, tile=128)
+    assert torch.equal(got, small)            # same K order per output element -> bitwise identical across tilings
+    x0 = torch.randn(M, N, generator=g)
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, gate=gate.to(gu.DEV),
+                  C_io=x0.clone().to(gu.DEV), tile=256)
+    assert gu.rel_err(got, x0 + gate * y) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
+
+
 def test_gemm_rejects_bad_shapes(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]

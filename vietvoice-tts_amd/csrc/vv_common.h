@@ -51,8 +51,11 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case VV_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case VV_ACT_SILU: return x / (1.0f + expf(-x));
         case VV_ACT_MISH: {
-            float sp = (x > 20.0f) ? x : log1pf(expf(x));
-            return x * tanhf(sp);
+            // x * tanh(softplus(x)) = x * t / (t + 2),  t = e^x (e^x + 2)   (one v_exp + one v_rcp)
+            if (x > 20.0f) return x;
+            const float n = __builtin_amdgcn_exp2f(1.4426950408889634f * x);
+            const float t = n * (n + 2.0f);
+            return x * t * __builtin_amdgcn_rcpf(t + 2.0f);
         }
         default: return x;
     }

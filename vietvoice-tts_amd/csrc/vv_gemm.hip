@@ -8,19 +8,18 @@
 // residual epilogues are lane-local and stores are 8/16-byte vectors.
 //
 //   bf16:  v_mfma_f32_16x16x32_bf16, BK = 64       fp32:  v_mfma_f32_32x32x2_f32, BK = 32
-//   tile 128(m) x 128(n), 4 waves (2x2), each wave 64x64, 64 accumulator registers.
+//   BIG   tile 256(m) x 256(n), 8 waves (2 x 4), wave = 128 m x 64 n, 128 accumulator registers,
+//         128 KiB LDS: one K-step is 64 MFMAs per wave (2 waves per SIMD), long enough to cover the
+//         LDS-DMA latency of the next tile with a plain double buffer.  Used when M >= 4096.
+//   SMALL tile 128 x 128, 4 waves (2 x 2), wave = 64 x 64: latency-sized problems (B = 1, time grid).
 //
-// Workgroup -> tile map is XCD-aware: the 8 XCDs (blockIdx % 8) each own whole 128-row
-// activation panels and walk all n-tiles of a panel back-to-back, so a panel is fetched from
-// HBM once into that XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
+// Workgroup -> tile map is XCD-aware: the 8 XCDs (blockIdx % 8) each own whole activation panels
+// and walk all n-tiles of a panel back-to-back, so a panel is fetched from HBM once into that
+// XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
 #include "vv_common.h"
 #include "vv_kernels.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128;
-constexpr int TILE_BYTES = 128 * 128;     // 128 rows x 128 B
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
 template <typename T> struct GemmTraits;
 template <> struct GemmTraits<bf16> { static constexpr int BK = 64; };
@@ -41,18 +40,24 @@ struct EpiArgs {
     int rope_dim;
 };
 
-template <int MODE, typename To>
-__device__ __forceinline__ void epi_apply(const EpiArgs& e, To* C, int ldc, int m, int pos, int n0, float v0, float v1,
-                                          float v2, float v3) {
-    if (e.bias) {
-        float4 b = *(const float4*)(e.bias + n0);
-        v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+// fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float epi_act(float x, int act) {
+    if (act == VV_ACT_GELU_TANH) {      // 0.5 x (1 + tanh(u)) == x * sigmoid(2u)
+        const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+        return x * fast_sigmoid(2.0f * u);
     }
+    if (act == VV_ACT_SILU) return x * fast_sigmoid(x);
+    if (act == VV_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    return x;
+}
+
+template <int MODE, typename To>
+__device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int m, int pos, int n0, float v0, float v1,
+                                          float v2, float v3) {
     if constexpr (MODE == MODE_STORE) {
-        if (e.act != VV_ACT_NONE) {
-            v0 = act_apply(v0, e.act); v1 = act_apply(v1, e.act);
-            v2 = act_apply(v2, e.act); v3 = act_apply(v3, e.act);
-        }
         if (n0 < e.n_store) store4<To>(C + (size_t)m * ldc + n0, v0, v1, v2, v3);
     } else if constexpr (MODE == MODE_QKV_ROPE) {
         if (n0 < 2 * e.rope_dim) {
@@ -69,7 +74,7 @@ __device__ __forceinline__ void epi_apply(const EpiArgs& e, To* C, int ldc, int 
         float* x = (float*)C + (size_t)m * ldc + n0;
         float4 r = *(const float4*)x;
         if (e.gate) {
-            float4 g = *(const float4*)(e.gate + n0);
+            const float4 g = *(const float4*)(e.gate + n0);
             r.x += g.x * v0; r.y += g.y * v1; r.z += g.z * v2; r.w += g.w * v3;
         } else {
             r.x += v0; r.y += v1; r.z += v2; r.w += v3;
@@ -78,26 +83,30 @@ __device__ __forceinline__ void epi_apply(const EpiArgs& e, To* C, int ldc, int 
     }
 }
 
-template <typename T, int MODE, typename To>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
-                                                      To* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e,
-                                                      int m_tiles, int n_tiles) {
+template <typename T, int MODE, typename To, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
+                                                                  int ldw, To* __restrict__ C, int ldc, int M, int N, int K,
+                                                                  EpiArgs e, int m_tiles, int n_tiles) {
     constexpr int BK = GemmTraits<T>::BK;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    constexpr int BT = BIG ? 256 : 128;            // tile edge (rows of A and rows of W)
+    constexpr int TILE_BYTES = BT * 128;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int MW = BIG ? 128 : 64;             // tokens per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | W tile)
 
-    // XCD-aware tile map (see header comment)
     const int id = blockIdx.x;
     const int xcd = id & 7, L = id >> 3;
     const int mt = (L / n_tiles) * 8 + xcd;
     const int nt = L % n_tiles;
     if (mt >= m_tiles) return;
-    const int bm = mt * BM, bn = nt * BN;
+    const int bm = mt * BT, bn = nt * BT;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BIG ? (wave >> 2) : (wave >> 1);
+    const int wc = BIG ? (wave & 3) : (wave & 1);
 
-    // ---- staging addresses: wave w issues LDS-DMA pieces q = 4w..4w+3 (8 rows x 128 B each) of both tiles
+    // ---- staging: a tile is BT/8 LDS-DMA pieces (8 rows x 128 B); every wave issues 4 pieces of each tile
     const char* a_src[4];
     const char* w_src[4];
 #pragma unroll
@@ -124,12 +133,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, i
     stage(0, 0);
 
     if constexpr (sizeof(T) == 2) {
-        // ------------------------------------------------ bf16: 4x4 tiles of 16x16x32
-        f32x4 acc[4][4];
+        // ------------------------------------------------ bf16: 4 x (MW/16) tiles of 16x16x32
+        constexpr int MI = MW / 16;
+        f32x4 acc[4][MI];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -139,39 +149,53 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, i
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 wf[4], af[4];
+                bf16x8 wf[4], af[MI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    wf[i] = *(const bf16x8*)(sw + swz128(wc * 64 + i * 16 + r16, ks * 4 + cq));
-                    af[i] = *(const bf16x8*)(sa + swz128(wr * 64 + i * 16 + r16, ks * 4 + cq));
-                }
+                for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(sw + swz128(wc * 64 + i * 16 + r16, ks * 4 + cq));
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + swz128(wr * MW + i * 16 + r16, ks * 4 + cq));
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
         }
-        // D[n_local = cq*4 + j][m_local = r16]
+        // ---- epilogue.  D[n_local = cq*4 + j][m_local = r16]; bias / activation hoisted out of the store loop
+        if (e.bias) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = bm + wr * 64 + mi * 16 + r16;
+            for (int ni = 0; ni < 4; ++ni) {
+                const float4 b = *(const float4*)(e.bias + bn + wc * 64 + ni * 16 + cq * 4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) { acc[ni][mi][0] += b.x; acc[ni][mi][1] += b.y; acc[ni][mi][2] += b.z; acc[ni][mi][3] += b.w; }
+            }
+        }
+        if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ni][mi][j] = epi_act(acc[ni][mi][j], e.act);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = bm + wr * MW + mi * 16 + r16;
             if (m >= M) continue;
             const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n0 = bn + wc * 64 + ni * 16 + cq * 4;
-                epi_apply<MODE, To>(e, C, ldc, m, pos, n0, acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2],
-                                    acc[ni][mi][3]);
-            }
+            for (int ni = 0; ni < 4; ++ni)
+                epi_store<MODE, To>(e, C, ldc, m, pos, bn + wc * 64 + ni * 16 + cq * 4, acc[ni][mi][0], acc[ni][mi][1],
+                                    acc[ni][mi][2], acc[ni][mi][3]);
         }
     } else {
-        // ------------------------------------------------ fp32: 2x2 tiles of 32x32x2 (exact f32 MFMA)
-        f32x16 acc[2][2];
+        // ------------------------------------------------ fp32: 2 x (MW/32) tiles of 32x32x2 (exact f32 MFMA)
+        constexpr int MI = MW / 32;
+        f32x16 acc[2][MI];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < MI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int r32 = lane & 31, h = lane >> 5;
@@ -184,46 +208,81 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, i
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 // lane half h takes chunk 2kk+h: the k pairing {4(2kk)+j, 4(2kk+1)+j} is the same for both operands
-                f32x4 wf[2], af[2];
+                f32x4 wf[2], af[MI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    wf[i] = *(const f32x4*)(sw + swz128(wc * 64 + i * 32 + r32, kk * 2 + h));
-                    af[i] = *(const f32x4*)(sa + swz128(wr * 64 + i * 32 + r32, kk * 2 + h));
-                }
+                for (int i = 0; i < 2; ++i) wf[i] = *(const f32x4*)(sw + swz128(wc * 64 + i * 32 + r32, kk * 2 + h));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const f32x4*)(sa + swz128(wr * MW + i * 32 + r32, kk * 2 + h));
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                        for (int ni = 0; ni < 2; ++ni)
                             acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ni][j], af[mi][j], acc[ni][mi], 0, 0, 0);
             }
         }
         // D[n_local = (reg&3) + 8(reg>>2) + 4h][m_local = r32]
+        if (e.bias) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int m = bm + wr * 64 + mi * 32 + r32;
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = *(const float4*)(e.bias + bn + wc * 64 + ni * 32 + g * 8 + h * 4);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        acc[ni][mi][g * 4 + 0] += b.x; acc[ni][mi][g * 4 + 1] += b.y;
+                        acc[ni][mi][g * 4 + 2] += b.z; acc[ni][mi][g * 4 + 3] += b.w;
+                    }
+                }
+        }
+        if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ni][mi][r] = epi_act(acc[ni][mi][r], e.act);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = bm + wr * MW + mi * 32 + r32;
             if (m >= M) continue;
             const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n0 = bn + wc * 64 + ni * 32 + g * 8 + h * 4;
-                    epi_apply<MODE, To>(e, C, ldc, m, pos, n0, acc[ni][mi][g * 4 + 0], acc[ni][mi][g * 4 + 1],
-                                        acc[ni][mi][g * 4 + 2], acc[ni][mi][g * 4 + 3]);
-                }
+                for (int g = 0; g < 4; ++g)
+                    epi_store<MODE, To>(e, C, ldc, m, pos, bn + wc * 64 + ni * 32 + g * 8 + h * 4, acc[ni][mi][g * 4 + 0],
+                                        acc[ni][mi][g * 4 + 1], acc[ni][mi][g * 4 + 2], acc[ni][mi][g * 4 + 3]);
         }
     }
 }
 
-template <typename T, int MODE, typename To>
-void launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
-            hipStream_t st) {
-    const int m_tiles = (M + BM - 1) / BM, n_tiles = N / BN;
+template <typename T, int MODE, typename To, bool BIG>
+hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
+                    hipStream_t st) {
+    constexpr int BT = BIG ? 256 : 128;
+    constexpr int LDS = 2 * 2 * BT * 128;
+    static bool attr_set = false;
+    auto kern = gemm_kernel<T, MODE, To, BIG>;
+    if (!attr_set) {
+        hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (he != hipSuccess) return he;
+        attr_set = true;
+    }
+    const int m_tiles = (M + BT - 1) / BT, n_tiles = N / BT;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    gemm_kernel<T, MODE, To><<<grid, 256, 0, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles,
-                                                    n_tiles);
+    kern<<<grid, BIG ? 512 : 256, LDS, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
+    return hipGetLastError();
+}
+
+template <typename T, int MODE, typename To>
+hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
+                  hipStream_t st, int force_tile) {
+    const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
+    if (big) return launch_t<T, MODE, To, true>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    return launch_t<T, MODE, To, false>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
 
 }  // namespace
@@ -233,11 +292,13 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     const int esz = g->dtype == VV_BF16 ? 2 : 4;
     const int BK = g->dtype == VV_BF16 ? 64 : 32;
     if (g->M <= 0 || g->N <= 0 || g->K <= 0) { *err = "gemm: empty shape"; return -22; }
-    if (g->N % BN != 0) { *err = "gemm: N must be a multiple of 128 (pad the weight rows)"; return -22; }
+    if (g->N % 128 != 0) { *err = "gemm: N must be a multiple of 128 (pad the weight rows)"; return -22; }
     if (g->K % BK != 0) { *err = "gemm: K must be a multiple of BK (64 bf16 / 32 f32)"; return -22; }
     if (((size_t)g->lda * esz) % 16 || ((size_t)g->ldw * esz) % 16 || ((uintptr_t)g->A % 16) || ((uintptr_t)g->W % 16) ||
         ((uintptr_t)g->C % 16) || (g->ldc % 4)) { *err = "gemm: operands must be 16-byte aligned"; return -22; }
     if (g->lda < g->K || g->ldw < g->K) { *err = "gemm: leading dimension smaller than K"; return -22; }
+    if (g->tile != 0 && g->tile != 128 && g->tile != 256) { *err = "gemm: tile must be 0 (auto), 128 or 256"; return -22; }
+    if (g->tile == 256 && g->N % 256) { *err = "gemm: the 256 tile needs N % 256 == 0"; return -22; }
     EpiArgs e;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
@@ -247,7 +308,8 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     }
     if (g->mode == MODE_GATE_RES && g->out_dtype != VV_F32) { *err = "gemm: residual stream is fp32"; return -22; }
     const bool bf = g->dtype == VV_BF16, obf = g->out_dtype == VV_BF16;
-#define GO(T, MODE, To) launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st)
+    hipError_t he = hipSuccess;
+#define GO(T, MODE, To) he = launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st, g->tile)
     if (g->mode == MODE_STORE) {
         if (bf && obf) GO(bf16, MODE_STORE, bf16);
         else if (bf) GO(bf16, MODE_STORE, float);
@@ -261,7 +323,6 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         if (bf) GO(bf16, MODE_GATE_RES, float); else GO(float, MODE_GATE_RES, float);
     } else { *err = "gemm: unknown epilogue mode"; return -22; }
 #undef GO
-    hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
     return 0;
 }
