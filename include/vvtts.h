@@ -36,6 +36,7 @@ extern "C" {
 #define VV_EPI_STORE 0     /* C = act(A W^T + bias)                         */
 #define VV_EPI_QKV_ROPE 1  /* C = rope(A W^T + bias) on the q and k columns */
 #define VV_EPI_GATE_RES 2  /* C += gate * (A W^T + bias)   (fp32 residual)  */
+#define VV_EPI_GATE_STORE 3 /* C = gate * (A W^T + bias); the add is fused into the next vv_layernorm (delta) */
 
 typedef struct vv_ctx vv_ctx;
 
@@ -139,6 +140,8 @@ typedef struct vv_ln_args {
     const float *w, *b;
     int32_t add_one;
     float eps;
+    const void* delta;      /* optional [R][ld_delta]: x += delta first (x is then updated in place) */
+    int32_t delta_dtype, ld_delta;
 } vv_ln_args;
 int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
 

@@ -73,6 +73,9 @@ def test_gemm_gate_residual(hip_tiny, dtype):
     got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, gate=gate.to(gu.DEV),
                   C_io=x0.clone().to(gu.DEV))
     assert gu.rel_err(got, ref) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
+    # gated store: the delta that the next LayerNorm adds to the residual stream
+    dl = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV))
+    assert gu.rel_err(dl, gate * (A.float() @ W.float().t() + b)) < _tol(dtype)
     ref1 = x0 + (A.float() @ W.float().t() + b)
     got1 = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, C_io=x0.clone().to(gu.DEV))
     assert gu.rel_err(got1, ref1) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
@@ -121,6 +124,9 @@ def test_gemm_big_tile(hip_tiny, dtype, M, N, K):
     got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, gate=gate.to(gu.DEV),
                   C_io=x0.clone().to(gu.DEV), tile=256)
     assert gu.rel_err(got, x0 + gate * y) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
+    dl = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=256)
+    assert gu.rel_err(dl, gate * y) < _tol(dtype)
+    assert torch.equal(dl, gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=128))
 
 
 def test_gemm_rejects_bad_shapes(hip_tiny):
@@ -209,6 +215,19 @@ def test_layernorm_modulate(hip_tiny, D, out_dtype):
         torch.cuda.synchronize()
         ref = F.layer_norm(x, (D,), eps=1e-6) * (sc + add_one) + sh
         assert gu.rel_err(y, ref) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
+    # fused residual add: x += delta (bf16 or fp32), written back, then normalised
+    for ddt in (torch.float32, torch.bfloat16):
+        dlt = (torch.randn(R, D, generator=g) * 0.5).to(ddt)
+        xx, dd = x.clone().to(gu.DEV), dlt.to(gu.DEV)
+        a = rt.vv_ln_args()
+        a.out_dtype = rt.VV_BF16 if out_dtype == torch.bfloat16 else rt.VV_F32
+        a.x, a.ldx, a.y, a.ldy, a.R, a.D, a.w, a.b, a.add_one, a.eps = xx.data_ptr(), D, y.data_ptr(), D, R, D, dsc.data_ptr(), dsh.data_ptr(), 1, 1e-6
+        a.delta, a.delta_dtype, a.ld_delta = dd.data_ptr(), (rt.VV_BF16 if ddt == torch.bfloat16 else rt.VV_F32), D
+        gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        xn = x + dlt.float()
+        assert torch.equal(xx.cpu(), xn)
+        assert gu.rel_err(y, F.layer_norm(xn, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
 
 
 # ------------------------------------------------------------------------------------ conv position embedding

@@ -405,14 +405,19 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
             KCHK(c, vvk_posconv(&a, st, &m__));
         }
+        // Residual stream protocol: a branch GEMM writes delta = gate * (out + bias) (operand dtype) into h2 and the NEXT
+        // LayerNorm kernel performs x += delta while it streams x anyway (no read-modify-write in a GEMM epilogue).
+        bool pending = false;
         for (int l = 0; l < g.depth; ++l) {
             const float* mod = c->modtab + ((size_t)l * S + s) * 6 * D;
             const std::string qkvw = blk(l, ".attn.qkv.weight"), qkvb = blk(l, ".attn.qkv.bias"), ow = blk(l, ".attn.out.weight"),
                               ob = blk(l, ".attn.out.bias"), f1w = blk(l, ".ff1.weight"), f1b = blk(l, ".ff1.bias"),
                               f2w = blk(l, ".ff2.weight"), f2b = blk(l, ".ff2.bias");
             vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
+            a.delta_dtype = c->dt; a.ld_delta = D;
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
-            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            a.delta = pending ? h2 : nullptr;
+            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
@@ -420,17 +425,20 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
                 Prof p(c, VV_PROF_ATTN, 4.0 * 2 * B * g.heads * (double)N * N * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
-            if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_GATE_RES, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), xres, D, (int)R, D, D, st, mod + 2 * D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D)) return r;
             a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
-            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            a.delta = h2;
+            { Prof p(c, VV_PROF_NORM, 0, 2 * (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
-            if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_GATE_RES, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), xres, D, (int)R, D, FF, st, mod + 5 * D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h2, D, (int)R, D, FF, st, mod + 5 * D)) return r;
+            pending = true;
         }
         {
             const float* fm = c->fintab + (size_t)s * 2 * D;
             vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
             a.w = fm; a.b = fm + D;                          // scale, shift
-            Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D, st);
+            a.delta = pending ? h2 : nullptr; a.delta_dtype = c->dt; a.ld_delta = D;
+            Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + es) * R * D : 0), st);
             KCHK(c, vvk_ln_mod(&a, st, &m__));
         }
         if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, h, D, "final.proj.weight", D, "final.proj.bias", pred, MP, (int)R, MP, D, st,

@@ -7,17 +7,20 @@
 
 namespace {
 
-// ---------------------------------------------------------------- K4: y = LN(x) * (w [+1]) + b
-// One wave per row, the row cached in registers (D <= 1024): one HBM read, one write.
-template <typename To>
-__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int ldx, To* __restrict__ y, int ldy,
+// ---------------------------------------------------------------- K4: [x += delta;] y = LN(x) * (w [+1]) + b
+// One wave per row, the row cached in registers (D <= 1024): one HBM read, one write.  When a
+// delta is given (the gated branch output of the previous GEMM) the residual add is fused here:
+// the fp32 stream is read once, updated, written back and normalised in the same pass.
+template <typename To, typename Td>
+__global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int ldx, To* __restrict__ y, int ldy,
                                                      int R, int D, const float* __restrict__ w,
-                                                     const float* __restrict__ b, int add_one, float eps) {
+                                                     const float* __restrict__ b, int add_one, float eps,
+                                                     const Td* __restrict__ delta, int ldd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const int n4 = D >> 2;
-    const float* xr = x + (size_t)row * ldx;
+    float* xr = x + (size_t)row * ldx;
     float4 v[4];
     float s = 0.f;
 #pragma unroll
@@ -25,6 +28,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
         const int c = lane + i * 64;
         if (c < n4) {
             v[i] = *(const float4*)(xr + c * 4);
+            if (delta) {
+                const float4 d = load4<Td>(delta + (size_t)row * ldd + c * 4);
+                v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
+                *(float4*)(xr + c * 4) = v[i];
+            }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -267,11 +275,16 @@ inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) /
 int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
     if (a->R <= 0) { *err = "ln: empty"; return -22; }
     if (a->D % 4 || a->D > 1024 || a->ldx % 4 || a->ldy % 4) { *err = "ln: D must be a multiple of 4 and <= 1024"; return -22; }
+    if (a->delta && (a->ld_delta % 4 || a->ld_delta < a->D)) { *err = "ln: bad delta leading dimension"; return -22; }
     const int grid = (a->R + 3) / 4;
-    if (a->out_dtype == VV_BF16)
-        ln_mod_kernel<bf16><<<grid, 256, 0, st>>>(a->x, a->ldx, (bf16*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps);
-    else
-        ln_mod_kernel<float><<<grid, 256, 0, st>>>(a->x, a->ldx, (float*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps);
+    float* x = const_cast<float*>(a->x);
+    const bool ob = a->out_dtype == VV_BF16, db = a->delta_dtype == VV_BF16;
+#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta)
+    if (ob && db) LN_GO(bf16, bf16);
+    else if (ob) LN_GO(bf16, float);
+    else if (db) LN_GO(float, bf16);
+    else LN_GO(float, float);
+#undef LN_GO
     VVK_CHECK_LAUNCH();
     return 0;
 }

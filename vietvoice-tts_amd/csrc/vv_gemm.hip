@@ -18,6 +18,8 @@
 // XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
 #include "vv_common.h"
 #include "vv_kernels.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -25,7 +27,7 @@ template <typename T> struct GemmTraits;
 template <> struct GemmTraits<bf16> { static constexpr int BK = 64; };
 template <> struct GemmTraits<float> { static constexpr int BK = 32; };
 
-enum { MODE_STORE = 0, MODE_QKV_ROPE = 1, MODE_GATE_RES = 2 };
+enum { MODE_STORE = 0, MODE_QKV_ROPE = 1, MODE_GATE_RES = 2, MODE_GATE_STORE = 3 };
 
 struct EpiArgs {
     const float* bias;
@@ -38,6 +40,7 @@ struct EpiArgs {
     int n_store;
     int seq_n;
     int rope_dim;
+    int dbg;     // timing-only ablations (tools/gemm_bench.py): bit0 = no wait/barrier, bit1 = no loads in the loop
 };
 
 // fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
@@ -59,6 +62,9 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
                                           float v2, float v3) {
     if constexpr (MODE == MODE_STORE) {
         if (n0 < e.n_store) store4<To>(C + (size_t)m * ldc + n0, v0, v1, v2, v3);
+    } else if constexpr (MODE == MODE_GATE_STORE) {      // C = gate * (A W^T + bias): the residual add is fused into the next LayerNorm
+        const float4 g = *(const float4*)(e.gate + n0);
+        store4<To>(C + (size_t)m * ldc + n0, g.x * v0, g.y * v1, g.z * v2, g.w * v3);
     } else if constexpr (MODE == MODE_QKV_ROPE) {
         if (n0 < 2 * e.rope_dim) {
             const bool is_k = n0 >= e.rope_dim;
@@ -83,15 +89,18 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
     }
 }
 
-template <typename T, int MODE, typename To, bool BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
+template <typename T, int MODE, typename To, int CFG>
+__global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 ? 4 : 2) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
                                                                   int ldw, To* __restrict__ C, int ldc, int M, int N, int K,
                                                                   EpiArgs e, int m_tiles, int n_tiles) {
     constexpr int BK = GemmTraits<T>::BK;
+    constexpr bool BIG = CFG != 0;
     constexpr int BT = BIG ? 256 : 128;            // tile edge (rows of A and rows of W)
     constexpr int TILE_BYTES = BT * 128;
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-    constexpr int MW = BIG ? 128 : 64;             // tokens per wave
+    constexpr int MW = CFG == 1 ? 128 : 64;        // tokens per wave
+    constexpr int NWAVE = CFG == 2 ? 16 : (CFG == 1 ? 8 : 4);
+    constexpr int PPW = BT / 8 / NWAVE;            // LDS-DMA pieces per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | W tile)
 
     const int id = blockIdx.x;
@@ -106,12 +115,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __res
     const int wr = BIG ? (wave >> 2) : (wave >> 1);
     const int wc = BIG ? (wave & 3) : (wave & 1);
 
-    // ---- staging: a tile is BT/8 LDS-DMA pieces (8 rows x 128 B); every wave issues 4 pieces of each tile
-    const char* a_src[4];
-    const char* w_src[4];
+    // ---- staging: a tile is BT/8 LDS-DMA pieces (8 rows x 128 B); every wave issues PPW pieces of each tile
+    const char* a_src[PPW];
+    const char* w_src[PPW];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = wave * 4 + u;
+    for (int u = 0; u < PPW; ++u) {
+        const int q = wave * PPW + u;
         const int row = q * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         const int gm = min(bm + row, M - 1);          // clamp: rows >= M are computed but never stored
@@ -122,8 +131,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __res
         char* base = smem + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * BK * sizeof(T);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = wave * 4 + u;
+        for (int u = 0; u < PPW; ++u) {
+            const int q = wave * PPW + u;
             glds16(a_src[u] + koff, base + q * 1024);
             glds16(w_src[u] + koff, base + TILE_BYTES + q * 1024);
         }
@@ -142,9 +151,11 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __res
             for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            if (!(e.dbg & 1)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            if (kt + 1 < nk && !(e.dbg & 2)) stage(kt + 1, (kt + 1) & 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -259,13 +270,277 @@ __global__ __launch_bounds__(BIG ? 512 : 256, 2) void gemm_kernel(const T* __res
     }
 }
 
-template <typename T, int MODE, typename To, bool BIG>
+
+// =====================================================================================================
+// bf16 ping-pong kernel (the throughput path): 256 x 256 tile, BK = 64, 8 waves = 2 groups x 4.
+//
+// Wave (g, wc) owns tokens g*128..+127 and features wc*64..+63; its K-tile work is four QUADRANT phases
+// (m-half, n-half) = (0,0) (0,1) (1,1) (1,0), 16 MFMAs each.  Each phase is two barrier-delimited
+// segments: L (LDS fragment reads for the phase + 2 LDS-DMA pieces of a future unit + counted vmcnt)
+// and C (the MFMA cluster).  Group 1 executes one extra barrier up front, so it always runs one
+// segment behind group 0: while one group's waves are in C, their SIMD partners are in L -- the
+// matrix pipe is fed across every barrier.
+//
+// LDS (128 KiB) = 2 K-tile parities x 4 units of 128 rows x 128 B (swz128), cut by CONSUMPTION ORDER:
+//   Wn0 (phase 0)  rows = for each wc: features wc*64 + 0..31      Am0 (phase 0)  rows = for each g: tokens g*128 + 0..63
+//   Wn1 (phase 1)                    features wc*64 + 32..63      Am1 (phase 2)                  tokens g*128 + 64..127
+// A unit is re-staged as soon as its last reader is a barrier behind, which is 5 phases (6 for Wn0)
+// before its next use: in K-tile T phase 0/1/2/3 the block stages Wn1(T+1) / Am1(T+1) / Wn0(T+2) /
+// Am0(T+2).  Every wave issues 2 pieces per phase, so "everything staged <= 4 phases ago has landed"
+// is s_waitcnt vmcnt(8) -- never 0 in steady state -- placed at the end of L(q), one barrier (two for
+// the other group) before the reads of phase q+1.
+// =====================================================================================================
+#define VV_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+__device__ __forceinline__ void wait_vm_staged(unsigned hist, int dbg) {
+    if (dbg & 32) return;                       // timing-only ablation
+    const int n = __builtin_popcount(hist & 0xF);
+    if (n == 4) VV_WAITVM(8);
+    else if (n == 3) VV_WAITVM(6);
+    else if (n == 2) VV_WAITVM(4);
+    else if (n == 1) VV_WAITVM(2);
+    else VV_WAITVM(0);
+}
+
+template <int MODE, typename To>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                                                         To* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, int m_tiles,
+                                                         int n_tiles) {
+    constexpr int UNIT = 128 * 128;                       // bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [parity 2][unit 4][UNIT]
+    const int id = blockIdx.x;
+    const int xcd = id & 7, L = id >> 3;
+    const int mt = (L / n_tiles) * 8 + xcd;
+    const int nt = L % n_tiles;
+    if (mt >= m_tiles) return;
+    const int bm = mt * 256, bn = nt * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = wave >> 2, wc = wave & 3;
+    const int r16 = lane & 15, cq = lane >> 4;
+
+    // ---- LDS-DMA sources: unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit
+    unsigned src_off[4][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ur = (wave * 2 + u) * 8 + (lane >> 3);              // row inside the unit
+        const unsigned cb = (unsigned)(((lane & 7) ^ ((ur >> 1) & 7)) * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = bn + (ur >> 5) * 64 + h * 32 + (ur & 31);
+            const int m = min(bm + (ur >> 6) * 128 + h * 64 + (ur & 63), M - 1);
+            src_off[2 * h][u] = (unsigned)n * (unsigned)ldw * 2u + cb;
+            src_off[2 * h + 1][u] = (unsigned)m * (unsigned)lda * 2u + cb;
+        }
+    }
+    auto stage = [&](auto type_c, int T) {
+        constexpr int type = decltype(type_c)::value;
+        const char* gbase = (type & 1) ? (const char*)A : (const char*)W;
+        char* slot = smem + ((T & 1) * 4 + type) * UNIT + wave * 2048;
+        if (e.dbg & 2) return;                  // timing-only ablation
+#pragma unroll
+        for (int u = 0; u < 2; ++u) glds16(gbase + (size_t)src_off[type][u] + (size_t)T * 128, slot + u * 1024);
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
+
+    // fragment addressing inside a unit: row = base16 + r16, chunk = ks*4 + cq  ->  swz128
+    unsigned lane_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) lane_off[ks] = (unsigned)((r16 << 7) | (((ks * 4 + cq) ^ ((r16 >> 1) & 7)) << 4));
+    const unsigned w_row0 = (unsigned)(wc * 32) << 7, a_row0 = (unsigned)(g * 64) << 7;
+
+    f32x4 acc[2][2][4][2];     // [m-half][n-half][mi][ni]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wfr[2][2][2];       // [n-half][ni][ks]
+    bf16x8 afr[4][2];          // [mi][ks]   (one m-half at a time)
+    if (e.dbg & 256) {
+        for (int i = 0; i < 8; ++i) { bf16x8 t; for (int j = 0; j < 8; ++j) t[j] = (bf16)(float)((lane * 7 + i * 3 + j) % 13 - 6); wfr[i >> 2][(i >> 1) & 1][i & 1] = t; afr[i >> 1][i & 1] = t; }
+    }
+
+    auto read_w = [&](int nh, const char* unit) {
+        if (e.dbg & 256) return;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wfr[nh][ni][ks] = *(const bf16x8*)(unit + w_row0 + (ni << 11) + lane_off[ks]);
+    };
+    auto read_a = [&](const char* unit) {
+        if (e.dbg & 256) return;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) afr[mi][ks] = *(const bf16x8*)(unit + a_row0 + (mi << 11) + lane_off[ks]);
+    };
+    auto cluster = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(e.dbg & 64)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nk = K >> 6;                                     // >= 2 (host-checked)
+    // prologue = phases -6..-1 of the staging schedule
+    stage(T0{}, 0); stage(T1{}, 0); stage(T2{}, 0); stage(T3{}, 0); stage(T0{}, 1); stage(T1{}, 1);
+    unsigned hist = 0xF;
+    VV_WAITVM(8);
+    bar();
+    if (g == 1) bar();                                         // stagger group 1 by one segment
+
+    for (int T = 0; T < nk; ++T) {
+        const char* base = smem + (T & 1) * (4 * UNIT);
+        bool st;
+        // ---- phase 0: quadrant (m0, n0)
+        read_w(0, base + 0 * UNIT);
+        read_a(base + 1 * UNIT);
+        st = T + 1 < nk; if (st) stage(T2{}, T + 1);
+        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
+        bar(); cluster(0, 0); bar();
+        // ---- phase 1: quadrant (m0, n1)
+        read_w(1, base + 2 * UNIT);
+        if (st) stage(T3{}, T + 1);
+        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
+        bar(); cluster(0, 1); bar();
+        // ---- phase 2: quadrant (m1, n1)
+        read_a(base + 3 * UNIT);
+        st = T + 2 < nk; if (st) stage(T0{}, T + 2);
+        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
+        bar(); cluster(1, 1); bar();
+        // ---- phase 3: quadrant (m1, n0)   (both W fragment sets are still in registers)
+        if (st) stage(T1{}, T + 2);
+        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
+        bar(); cluster(1, 0); bar();
+    }
+    if (g == 0) bar();                                         // balance group 1's extra barrier
+
+    // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n0 = bn + wc * 64 + nh * 32 + ni * 16 + cq * 4;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.bias) b = *(const float4*)(e.bias + n0);
+            float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (MODE == MODE_GATE_STORE) gt = *(const float4*)(e.gate + n0);
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    f32x4& v = acc[mh][nh][mi][ni];
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = epi_act(v[j], e.act);
+                    }
+                    if (MODE == MODE_GATE_STORE) { v[0] *= gt.x; v[1] *= gt.y; v[2] *= gt.z; v[3] *= gt.w; }
+                }
+        }
+    if constexpr (sizeof(To) == 2 && MODE != MODE_GATE_RES) {
+        // bf16 output: transpose through the (now idle) LDS so that global stores are whole 128-byte rows.
+        // Wave-private 16 KiB region: 128 tokens x 64 features, 16-byte chunk index XOR (row & 7).
+        char* stg = smem + wave * 16384;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = mh * 64 + mi * 16 + r16;
+                const int m = bm + g * 128 + row;
+                const int pos = (MODE == MODE_QKV_ROPE) ? (min(m, M - 1) % e.seq_n) : 0;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        f32x4 v = acc[mh][nh][mi][ni];
+                        const int nl = nh * 32 + ni * 16 + cq * 4;               // feature inside the wave's 64
+                        if constexpr (MODE == MODE_QKV_ROPE) {
+                            const int n0 = bn + wc * 64 + nl;
+                            if (n0 < 2 * e.rope_dim) {
+                                const bool is_k = n0 >= e.rope_dim;
+                                const int d = n0 & 63;
+                                const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
+                                const float4 s = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
+                                const float o0 = v[0] * c.x - v[1] * s.x, o1 = v[1] * c.y + v[0] * s.y;
+                                const float o2 = v[2] * c.z - v[3] * s.z, o3 = v[3] * c.w + v[2] * s.w;
+                                v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                            }
+                        }
+                        const int chunk = (nl >> 3) ^ (row & 7);
+                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *(bf16x4*)(stg + row * 128 + chunk * 16 + (nl & 4) * 2) = pk;
+                    }
+            }
+        // same wave reads its own region back: no barrier, the compiler's lgkmcnt wait orders it
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int ch = lane & 7;
+            const uint4 val = *(const uint4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int m = bm + g * 128 + row;
+            const int n0 = bn + wc * 64 + ch * 8;
+            if (m < M && n0 < e.n_store && !((e.dbg & 128) && m != 0x7fffffff)) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
+        }
+    } else {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = bm + g * 128 + mh * 64 + mi * 16 + r16;
+                if (m >= M || ((e.dbg & 128) && m != 0x7fffffff)) continue;
+                const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const f32x4 v = acc[mh][nh][mi][ni];
+                        const int n0 = bn + wc * 64 + nh * 32 + ni * 16 + cq * 4;
+                        if constexpr (MODE == MODE_GATE_STORE) store4<To>(C + (size_t)m * ldc + n0, v[0], v[1], v[2], v[3]);
+                        else epi_store<MODE, To>(e, C, ldc, m, pos, n0, v[0], v[1], v[2], v[3]);
+                    }
+            }
+    }
+}
+
+template <int MODE, typename To>
+hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
+                     hipStream_t st) {
+    constexpr int LDS = 2 * 4 * 128 * 128;
+    static bool attr_set = false;
+    auto kern = gemm_pp_kernel<MODE, To>;
+    if (!attr_set) {
+        hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (he != hipSuccess) return he;
+        attr_set = true;
+    }
+    const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
+    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    kern<<<grid, 512, LDS, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
+    return hipGetLastError();
+}
+
+template <typename T, int MODE, typename To, int CFG>
 hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                     hipStream_t st) {
-    constexpr int BT = BIG ? 256 : 128;
+    constexpr int BT = CFG ? 256 : 128;
     constexpr int LDS = 2 * 2 * BT * 128;
     static bool attr_set = false;
-    auto kern = gemm_kernel<T, MODE, To, BIG>;
+    auto kern = gemm_kernel<T, MODE, To, CFG>;
     if (!attr_set) {
         hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (he != hipSuccess) return he;
@@ -273,7 +548,7 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
     }
     const int m_tiles = (M + BT - 1) / BT, n_tiles = N / BT;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    kern<<<grid, BIG ? 512 : 256, LDS, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
+    kern<<<grid, CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), LDS, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
     return hipGetLastError();
 }
 
@@ -281,8 +556,14 @@ template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                   hipStream_t st, int force_tile) {
     const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
-    if (big) return launch_t<T, MODE, To, true>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
-    return launch_t<T, MODE, To, false>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    if constexpr (sizeof(T) == 2) {
+        // bf16 throughput path: ping-pong kernel (byte offsets are 32-bit: operands must stay below 4 GiB)
+        if (big && !(e.dbg & 12) && K >= 128 && (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldw * 2 < ((size_t)1 << 32))
+            return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    }
+    if (big && (e.dbg & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
 
 }  // namespace
@@ -303,6 +584,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.rope_dim = g->rope_dim;
+    { const char* d = getenv("VV_GEMM_DBG"); e.dbg = d ? atoi(d) : 0; }
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {
         *err = "gemm: rope epilogue needs the four tables and rope_dim % 64 == 0"; return -22;
     }
@@ -321,6 +603,11 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         else { *err = "gemm: qkv epilogue writes the operand dtype"; return -22; }
     } else if (g->mode == MODE_GATE_RES) {
         if (bf) GO(bf16, MODE_GATE_RES, float); else GO(float, MODE_GATE_RES, float);
+    } else if (g->mode == MODE_GATE_STORE) {
+        if (!g->gate) { *err = "gemm: gated store needs a gate vector"; return -22; }
+        if (bf && obf) GO(bf16, MODE_GATE_STORE, bf16);
+        else if (!bf && !obf) GO(float, MODE_GATE_STORE, float);
+        else { *err = "gemm: gated store writes the operand dtype"; return -22; }
     } else { *err = "gemm: unknown epilogue mode"; return -22; }
 #undef GO
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
