@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from vietvoice_tts_amd import pack  # noqa: E402
+from vietvoice_tts_amd import pack, sharding  # noqa: E402,F401
 from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights  # noqa: E402
 from vietvoice_tts_amd.runtime import HipSynth  # noqa: E402
 
@@ -125,24 +125,14 @@ def main():
 
     spec = {"full": ModelSpec.full, "small": ModelSpec.small, "tiny": ModelSpec.tiny}[a.spec]()
     adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    table, total = pack.plan(spec, adt)
-    weights = None
-    if rank == 0:
-        weights = make_synthetic_weights(spec, SEED)
-        cpu = torch.zeros(total, dtype=torch.uint8)
-        pack.fill(spec, adt, weights, cpu)
-        flat = cpu.to(device)
-        del cpu
-    else:
-        flat = torch.empty(total, dtype=torch.uint8, device=device)
-    bcast_ms = None
+    weights = make_synthetic_weights(spec, SEED) if rank == 0 else None
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
-        t0 = time.perf_counter()
-        dist.broadcast(flat, src=0)          # C1: the only collective; RCCL over xGMI
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    flat, _table = sharding.broadcast_weights(spec, adt, weights, device)      # C1: the only collective; RCCL over xGMI
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
     d, N = make_inputs(spec, a.batch, rank, device)
 
@@ -205,7 +195,7 @@ def main():
         "roofline": roofline, "kernel_classes": classes,
     }
     if bcast_ms is not None:
-        res["weight_broadcast_ms"] = round(bcast_ms, 2)
+        res["weight_pack_and_broadcast_ms"] = round(bcast_ms, 2)
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(spec, weights, a.nfe)
     print(json.dumps(res), flush=True)

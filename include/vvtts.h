@@ -119,6 +119,7 @@ typedef struct vv_gemm_args {
     int32_t M, N, K;
     const float *bias, *gate, *cos_q, *sin_q, *cos_k, *sin_k;
     int32_t n_store, seq_n, rope_dim;
+    const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
     int32_t tile;   /* 0 = auto (256x256 tile when M >= 4096 and N % 256 == 0), 128 or 256 to force */
 } vv_gemm_args;
 int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
@@ -173,6 +174,8 @@ int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16
                  int B, int C, int T, int KW, float pre_slope, const int32_t* len_in, void* stream);
 int vv_mel(vv_ctx* ctx, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max,
            void* stream);
+/* out[pos][2i] = cos[pos][2i], out[pos][2i+1] = sin[pos][2i]  (tables with duplicated pairs, n rows x 64) */
+int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
 int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
 
 #ifdef __cplusplus

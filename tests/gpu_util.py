@@ -36,7 +36,9 @@ def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=No
     a.bias = None if bias is None else bias.data_ptr()
     a.gate = None if gate is None else gate.data_ptr()
     if ropes is not None:
-        a.cos_q, a.sin_q, a.cos_k, a.sin_k = [t.data_ptr() for t in ropes]
+        a.cos_q, a.sin_q, a.cos_k, a.sin_k = [t.data_ptr() for t in ropes[:4]]
+        if len(ropes) == 6:
+            a.rope_cs_q, a.rope_cs_k = ropes[4].data_ptr(), ropes[5].data_ptr()
     a.n_store, a.seq_n, a.rope_dim, a.tile = n_store, seq_n, rope_dim, tile
     check(eng, eng.lib.vv_gemm(eng.ctx, C.byref(a), stream()))
     torch.cuda.synchronize()

@@ -100,9 +100,15 @@ def test_gemm_qkv_rope(hip_tiny, dtype, tiny_setup):
     qr = Oracle.rope_apply(q.reshape(M, 2, 64), pos_tab[0], pos_tab[1]).reshape(M, D)
     kr = Oracle.rope_apply(k.reshape(M, 2, 64), pos_tab[2], pos_tab[3]).reshape(M, D)
     ref = torch.cat([qr, kr, v], dim=-1)
-    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=[t.contiguous().to(gu.DEV) for t in ropes],
-                  seq_n=seq_n, rope_dim=D)
+    dr = [t.contiguous().to(gu.DEV) for t in ropes]
+    got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=dr, seq_n=seq_n, rope_dim=D)
     assert gu.rel_err(got, ref) < _tol(dtype)
+    # compact (cos, sin) pair tables + the persistent 256-tile kernel (bf16) must give the same rotation
+    cs = [torch.zeros(seq_n, 64, device=gu.DEV) for _ in range(2)]
+    for i in range(2):
+        gu.check(eng, eng.lib.vv_rope_compact(eng.ctx, dr[2 * i].data_ptr(), dr[2 * i + 1].data_ptr(), cs[i].data_ptr(), seq_n, gu.stream()))
+    got2 = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=dr + cs, seq_n=seq_n, rope_dim=D, tile=128)
+    assert gu.rel_err(got2, ref) < _tol(dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -119,14 +125,14 @@ def test_gemm_big_tile(hip_tiny, dtype, M, N, K):
     got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), act=1, tile=256)
     assert gu.rel_err(got, F.gelu(y, approximate="tanh")) < _tol(dtype)
     small = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), act=1, tile=128)
-    assert torch.equal(got, small)            # same K order per output element -> bitwise identical across tilings
+    assert gu.rel_err(got, small.float()) < (8e-3 if dtype == torch.bfloat16 else 1e-6)   # tilings agree to rounding (bias enters first in the persistent kernel)
     x0 = torch.randn(M, N, generator=g)
     got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=2, out_dtype=rt.VV_F32, gate=gate.to(gu.DEV),
                   C_io=x0.clone().to(gu.DEV), tile=256)
     assert gu.rel_err(got, x0 + gate * y) < (2e-3 if dtype == torch.bfloat16 else TOL_F32)
     dl = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=256)
     assert gu.rel_err(dl, gate * y) < _tol(dtype)
-    assert torch.equal(dl, gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=128))
+    assert gu.rel_err(dl, gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=128).float()) < (8e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
 def test_gemm_rejects_bad_shapes(hip_tiny):

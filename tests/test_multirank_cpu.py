@@ -1,0 +1,66 @@
+"""-m "not gpu": the N > 1 path on CPU with the gloo backend, world_size 2 (the GPU job uses the same
+code with backend nccl = RCCL).  Covers the one collective (flat weight broadcast) and the unit sharding."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vietvoice_tts_amd import pack, sharding
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    spec = ModelSpec.tiny()
+    w = make_synthetic_weights(spec, 9527) if rank == 0 else None
+    flat, table = sharding.broadcast_weights(spec, torch.bfloat16, w, torch.device("cpu"))
+    # every rank can rebuild the reference packing locally and must have received exactly those bytes
+    ref = torch.zeros(pack.plan(spec, torch.bfloat16)[1], dtype=torch.uint8)
+    pack.fill(spec, torch.bfloat16, make_synthetic_weights(spec, 9527), ref)
+    ok_bytes = bool(torch.equal(flat, ref))
+    frames = [1600, 900, 1600, 400, 1200, 1600, 700, 1000, 300]
+    mine = sharding.shard_units([sharding.unit_cost(f) for f in frames], world)[rank]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, ok_bytes, int(flat.sum()), gathered, len(table)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(r[1] for r in res), "a rank did not receive the packed weights bit-exactly"
+    assert res[0][2] == res[1][2] and res[0][4] == res[1][4]
+    shards = res[0][3]
+    assert sorted(shards[0] + shards[1]) == list(range(9))                 # a partition: every unit once
+    from vietvoice_tts_amd import sharding
+    costs = [sharding.unit_cost(f) for f in [1600, 900, 1600, 400, 1200, 1600, 700, 1000, 300]]
+    load = [sum(costs[i] for i in s) for s in shards]
+    assert max(load) / min(load) < 1.25                                     # LPT keeps the ranks balanced
+
+
+def test_shard_units_properties():
+    from vietvoice_tts_amd import sharding
+    assert sharding.shard_units([], 4) == [[], [], [], []]
+    eq = sharding.shard_units([1.0] * 64, 8)
+    assert all(len(s) == 8 for s in eq) and sorted(sum(eq, [])) == list(range(64))
+    one = sharding.shard_units([3.0, 1.0, 2.0], 1)
+    assert one == [[0, 1, 2]]

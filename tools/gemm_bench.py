@@ -31,6 +31,7 @@ def main():
         a.bias, a.gate = bias.data_ptr(), (gate.data_ptr() if mode >= 2 else None)
         if mode == 1:
             a.cos_q = a.sin_q = a.cos_k = a.sin_k = cq.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
+            a.rope_cs_q = a.rope_cs_k = cq.data_ptr()
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
             assert eng.lib.vv_gemm(eng.ctx, C.byref(a), st) == 0, eng.lib.vv_last_error(eng.ctx)

@@ -115,11 +115,12 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1) {
+    // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
     g.A = A; g.lda = lda; g.W = c->W(wname); g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
-    if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; }
+    if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -367,7 +368,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     const int S = c->n_steps;
     Need nd;
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
-    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B);
+    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64);
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
@@ -378,7 +379,11 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     char* ffm = carve<char>(c, es * R * FF);
     float* pred = carve<float>(c, R * MP);
     int* kv_len = carve<int>(c, 2 * B);
-    const float* rope[4] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k};
+    float* csq = carve<float>(c, (size_t)N * 64);
+    float* csk = carve<float>(c, (size_t)N * 64);
+    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, csq, csk};
+    KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
+    KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
 
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
@@ -590,6 +595,9 @@ int vv_mel(vv_ctx* c, const int16_t* audio, int ld_audio, const int32_t* audio_l
         return c->fail(-2, "vv_mel: constant tables not bound");
     SINGLE(c, vvk_mel(audio, ld_audio, audio_len, c->Wf("const.window"), c->Wf("const.tw_cos"), c->Wf("const.tw_sin"), c->Wf("const.mel_fb"),
                       mel, B, F_max, c->cfg.n_fft, c->cfg.hop_length, c->cfg.n_mel, (hipStream_t)st, &m__));
+}
+int vv_rope_compact(vv_ctx* c, const float* cos_t, const float* sin_t, float* out, int n, void* st) {
+    SINGLE(c, vvk_rope_compact(cos_t, sin_t, out, n, (hipStream_t)st, &m__));
 }
 int vv_cfg_euler(vv_ctx* c, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* st) {
     SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, (hipStream_t)st, &m__));

@@ -247,6 +247,14 @@ __global__ void dup_len_kernel(const int* __restrict__ seq_len, int* __restrict_
     if (b < B) { out[b] = seq_len[b]; out[B + b] = seq_len[b]; }
 }
 
+__global__ __launch_bounds__(256) void rope_compact_kernel(const float* __restrict__ c, const float* __restrict__ s, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // one (pos, pair)
+    if (i >= n * 32) return;
+    const int pos = i >> 5, pr = i & 31;
+    out[(size_t)pos * 64 + 2 * pr] = c[(size_t)pos * 64 + 2 * pr];
+    out[(size_t)pos * 64 + 2 * pr + 1] = s[(size_t)pos * 64 + 2 * pr];
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(float* __restrict__ x, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = x[i];
@@ -361,6 +369,12 @@ int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int
 }
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err) {
     dup_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(seq_len, out, B);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err) {
+    if (n <= 0) { *err = "rope_compact: empty"; return -22; }
+    rope_compact_kernel<<<(n * 32 + 255) / 256, 256, 0, st>>>(c, s, out, n);
     VVK_CHECK_LAUNCH();
     return 0;
 }

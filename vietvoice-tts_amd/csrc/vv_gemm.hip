@@ -36,6 +36,8 @@ struct EpiArgs {
     const float* sin_q;
     const float* cos_k;
     const float* sin_k;
+    const float* cs_q;       // optional compact tables [pos][64] = (cos, sin) per pair, pair-duplicated tables only
+    const float* cs_k;
     int act;
     int n_store;
     int seq_n;
@@ -291,54 +293,57 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
 // the other group) before the reads of phase q+1.
 // =====================================================================================================
 #define VV_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-__device__ __forceinline__ void wait_vm_staged(unsigned hist, int dbg) {
-    if (dbg & 32) return;                       // timing-only ablation
-    const int n = __builtin_popcount(hist & 0xF);
-    if (n == 4) VV_WAITVM(8);
-    else if (n == 3) VV_WAITVM(6);
-    else if (n == 2) VV_WAITVM(4);
-    else if (n == 1) VV_WAITVM(2);
-    else VV_WAITVM(0);
-}
 
 template <int MODE, typename To>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                          To* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, int m_tiles,
                                                          int n_tiles) {
     constexpr int UNIT = 128 * 128;                       // bytes
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [parity 2][unit 4][UNIT]
-    const int id = blockIdx.x;
-    const int xcd = id & 7, L = id >> 3;
-    const int mt = (L / n_tiles) * 8 + xcd;
-    const int nt = L % n_tiles;
-    if (mt >= m_tiles) return;
-    const int bm = mt * 256, bn = nt * 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [parity 2][unit 4][UNIT] | 8 x 4 KiB epilogue staging
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = wave >> 2, wc = wave & 3;
     const int r16 = lane & 15, cq = lane >> 4;
 
-    // ---- LDS-DMA sources: unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit
-    unsigned src_off[4][2];
+    // ---- persistent tile walk, XCD-aware: block b serves XCD label x = b & 7 (blocks b, b+8 share an L2); that
+    // XCD owns activation panels x, x+8, ... and its blocks walk the (panel, n-tile) list panel-major, so
+    // the panel's re-reads by the other n-tiles hit the same L2.  Placement changes speed only.
+    const int x = blockIdx.x & 7, jb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int n_entries = (m_tiles > x ? (m_tiles - x + 7) / 8 : 0) * n_tiles;
+    if (jb >= n_entries) return;
+    const int n_my = (n_entries - jb + bpx - 1) / bpx;
+    auto tile_bm = [&](int i) { return (((jb + i * bpx) / n_tiles) * 8 + x) * 256; };
+    auto tile_bn = [&](int i) { return ((jb + i * bpx) % n_tiles) * 256; };
+
+    // ---- LDS-DMA sources (buffer_load ... lds): per-lane 32-bit voffset + SGPR soffset (tile origin, K advance).
+    // unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit.
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+    unsigned voff_w[2][2];     // [n-half][piece]  relative to the tile's first weight row
+    int loc_a[2];              // [piece]          token row of the piece inside the tile (m-half 0); + 64 for m-half 1
+    unsigned cbyte[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int ur = (wave * 2 + u) * 8 + (lane >> 3);              // row inside the unit
-        const unsigned cb = (unsigned)(((lane & 7) ^ ((ur >> 1) & 7)) * 16);
+        cbyte[u] = (unsigned)(((lane & 7) ^ ((ur >> 1) & 7)) * 16);
+        loc_a[u] = (ur >> 6) * 128 + (ur & 63);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = bn + (ur >> 5) * 64 + h * 32 + (ur & 31);
-            const int m = min(bm + (ur >> 6) * 128 + h * 64 + (ur & 63), M - 1);
-            src_off[2 * h][u] = (unsigned)n * (unsigned)ldw * 2u + cb;
-            src_off[2 * h + 1][u] = (unsigned)m * (unsigned)lda * 2u + cb;
-        }
+        for (int h = 0; h < 2; ++h) voff_w[h][u] = (unsigned)((ur >> 5) * 64 + h * 32 + (ur & 31)) * (unsigned)ldw * 2u + cbyte[u];
     }
-    auto stage = [&](auto type_c, int T) {
+    // stage unit `type` of K-tile Tk (parity par) of the tile whose origin is (bmS, bnS)
+    auto stage = [&](auto type_c, int bmS, int bnS, int Tk, int par) {
         constexpr int type = decltype(type_c)::value;
-        const char* gbase = (type & 1) ? (const char*)A : (const char*)W;
-        char* slot = smem + ((T & 1) * 4 + type) * UNIT + wave * 2048;
-        if (e.dbg & 2) return;                  // timing-only ablation
+        constexpr int h = type >> 1;
+        char* slot = smem + (par * 4 + type) * UNIT + wave * 2048;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) glds16(gbase + (size_t)src_off[type][u] + (size_t)T * 128, slot + u * 1024);
+        for (int u = 0; u < 2; ++u) {
+            if constexpr (type & 1) {
+                const unsigned v = (unsigned)min(bmS + loc_a[u] + h * 64, M - 1) * (unsigned)lda * 2u + cbyte[u];   // clamp: rows >= M never stored
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(slot + u * 1024), 16, (int)v, Tk * 128, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(slot + u * 1024), 16, (int)voff_w[h][u], bnS * ldw * 2 + Tk * 128, 0, 0);
+            }
+        }
     };
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
     using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
@@ -350,29 +355,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     const unsigned w_row0 = (unsigned)(wc * 32) << 7, a_row0 = (unsigned)(g * 64) << 7;
 
     f32x4 acc[2][2][4][2];     // [m-half][n-half][mi][ni]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 wfr[2][2][2];       // [n-half][ni][ks]
     bf16x8 afr[4][2];          // [mi][ks]   (one m-half at a time)
-    if (e.dbg & 256) {
-        for (int i = 0; i < 8; ++i) { bf16x8 t; for (int j = 0; j < 8; ++j) t[j] = (bf16)(float)((lane * 7 + i * 3 + j) % 13 - 6); wfr[i >> 2][(i >> 1) & 1][i & 1] = t; afr[i >> 1][i & 1] = t; }
-    }
 
     auto read_w = [&](int nh, const char* unit) {
-        if (e.dbg & 256) return;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) wfr[nh][ni][ks] = *(const bf16x8*)(unit + w_row0 + (ni << 11) + lane_off[ks]);
     };
     auto read_a = [&](const char* unit) {
-        if (e.dbg & 256) return;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -391,145 +383,219 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        if (!(e.dbg & 64)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-
     const int nk = K >> 6;                                     // >= 2 (host-checked)
-    // prologue = phases -6..-1 of the staging schedule
-    stage(T0{}, 0); stage(T1{}, 0); stage(T2{}, 0); stage(T3{}, 0); stage(T0{}, 1); stage(T1{}, 1);
-    unsigned hist = 0xF;
+    // One K-tile = four phases.  The staging schedule is continuous across tiles: K-tile T of the current tile
+    // stages Wn1/Am1 of K-tile T+1 and Wn0/Am0 of K-tile T+2, which roll over into the NEXT tile of this
+    // block at the end (its first units land while this tile finishes and runs its epilogue).  Every phase
+    // stages, so the counted wait is always vmcnt(8): everything staged more than four phases ago has landed.
+    // The last tile of a block "prefetches" itself again (harmless: those slots are free), which keeps the
+    // loop free of conditionals; the kernel drains with vmcnt(0) before it exits.
+    auto ktile = [&](int T, int par, int bm_c, int bn_c, int bm_n, int bn_n) {
+        const char* base = smem + par * (4 * UNIT);
+        const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
+        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? T + 1 - nk : T + 1;
+        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? T + 2 - nk : T + 2;
+        // ---- phase 0: quadrant (m0, n0)
+        read_w(0, base + 0 * UNIT);
+        read_a(base + 1 * UNIT);
+        stage(T2{}, bm1, bn1, t1, par ^ 1);
+        VV_WAITVM(8); bar(); cluster(0, 0); bar();
+        // ---- phase 1: quadrant (m0, n1)
+        read_w(1, base + 2 * UNIT);
+        stage(T3{}, bm1, bn1, t1, par ^ 1);
+        VV_WAITVM(8); bar(); cluster(0, 1); bar();
+        // ---- phase 2: quadrant (m1, n1)
+        read_a(base + 3 * UNIT);
+        stage(T0{}, bm2, bn2, t2, par);
+        VV_WAITVM(8); bar(); cluster(1, 1); bar();
+        // ---- phase 3: quadrant (m1, n0)   (both W fragment sets are still in registers)
+        stage(T1{}, bm2, bn2, t2, par);
+        VV_WAITVM(8); bar(); cluster(1, 0); bar();
+    };
+
+    // prologue = phases -6..-1 of the staging schedule for this block's first tile
+    {
+        const int bm0 = tile_bm(0), bn0 = tile_bn(0);
+        stage(T0{}, bm0, bn0, 0, 0); stage(T1{}, bm0, bn0, 0, 0); stage(T2{}, bm0, bn0, 0, 0); stage(T3{}, bm0, bn0, 0, 0);
+        stage(T0{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);
+    }
     VV_WAITVM(8);
     bar();
     if (g == 1) bar();                                         // stagger group 1 by one segment
 
-    for (int T = 0; T < nk; ++T) {
-        const char* base = smem + (T & 1) * (4 * UNIT);
-        bool st;
-        // ---- phase 0: quadrant (m0, n0)
-        read_w(0, base + 0 * UNIT);
-        read_a(base + 1 * UNIT);
-        st = T + 1 < nk; if (st) stage(T2{}, T + 1);
-        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
-        bar(); cluster(0, 0); bar();
-        // ---- phase 1: quadrant (m0, n1)
-        read_w(1, base + 2 * UNIT);
-        if (st) stage(T3{}, T + 1);
-        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
-        bar(); cluster(0, 1); bar();
-        // ---- phase 2: quadrant (m1, n1)
-        read_a(base + 3 * UNIT);
-        st = T + 2 < nk; if (st) stage(T0{}, T + 2);
-        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
-        bar(); cluster(1, 1); bar();
-        // ---- phase 3: quadrant (m1, n0)   (both W fragment sets are still in registers)
-        if (st) stage(T1{}, T + 2);
-        hist = (hist << 1) | (unsigned)st; wait_vm_staged(hist, e.dbg);
-        bar(); cluster(1, 0); bar();
-    }
-    if (g == 0) bar();                                         // balance group 1's extra barrier
+    int G = 0;                                                 // global K-tile counter (LDS parity)
+    for (int it = 0; it < n_my; ++it) {
+        const int bm = tile_bm(it), bn = tile_bn(it);
+        const bool last = it + 1 == n_my;
+        const int bm_n = last ? bm : tile_bm(it + 1), bn_n = last ? bn : tile_bn(it + 1);
+        // accumulators start at the bias (feature-only), so the epilogue has no bias pass
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[mh][nh][mi][ni] = b4;
+            }
+        for (int T = 0; T < nk; ++T, ++G) ktile(T, G & 1, bm, bn, bm_n, bn_n);
 
-    // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
+        // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
+        if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
+            const float k1 = e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f;
+            const float k3 = e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f;
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+            for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int n0 = bn + wc * 64 + nh * 32 + ni * 16 + cq * 4;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e.bias) b = *(const float4*)(e.bias + n0);
-            float4 gt = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (MODE == MODE_GATE_STORE) gt = *(const float4*)(e.gate + n0);
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float xv = acc[mh][nh][mi][ni][j];
+                                acc[mh][nh][mi][ni][j] = xv * fast_sigmoid(xv * (k1 + k3 * xv * xv));   // x * sigmoid(2u) == 0.5 x (1 + tanh u)
+                            }
+        }
+        if constexpr (MODE == MODE_GATE_STORE) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float4 gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            f32x4& v = acc[mh][nh][mi][ni];
+                            v[0] *= gt.x; v[1] *= gt.y; v[2] *= gt.z; v[3] *= gt.w;
+                        }
+                }
+        }
+        if constexpr (sizeof(To) == 2 && MODE != MODE_GATE_RES) {
+            // bf16 output: transpose through a wave-private 4 KiB LDS region (32 tokens x 64 features per pass, 16-byte
+            // chunk index XOR (row & 7)) so that global stores are whole 128-byte rows.  The unit slots are NOT
+            // touched: the next tile's first units are landing there.
+            char* stg = smem + 8 * UNIT + wave * 4096;
+            if (!(e.dbg & 512))
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int mh = ps >> 1;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int mi = (ps & 1) * 2 + k;
+                    const int lr = k * 16 + r16;
+                    const int m = bm + g * 128 + ps * 32 + lr;
+                    const int pos = (MODE == MODE_QKV_ROPE) ? (min(m, M - 1) % e.seq_n) : 0;
+                    // RoPE: one 16-byte (cos, sin, cos, sin) load per 4 outputs from the compact table, all four issued first
+                    float4 cs4[2][2];
+                    bool do_rope = false;
+                    if constexpr (MODE == MODE_QKV_ROPE) {
+                        do_rope = bn + wc * 64 < 2 * e.rope_dim && e.cs_q != nullptr;
+                        if (do_rope) {
+                            const float* tab = (bn + wc * 64 >= e.rope_dim ? e.cs_k : e.cs_q) + (size_t)pos * 64;
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                                for (int ni = 0; ni < 2; ++ni) cs4[nh][ni] = *(const float4*)(tab + nh * 32 + ni * 16 + cq * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            f32x4 v = acc[mh][nh][mi][ni];
+                            const int nl = nh * 32 + ni * 16 + cq * 4;               // feature inside the wave's 64
+                            if constexpr (MODE == MODE_QKV_ROPE) {
+                                if (do_rope) {
+                                    const float4 t = cs4[nh][ni];
+                                    const float o0 = v[0] * t.x - v[1] * t.y, o1 = v[1] * t.x + v[0] * t.y;
+                                    const float o2 = v[2] * t.z - v[3] * t.w, o3 = v[3] * t.z + v[2] * t.w;
+                                    v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                                } else {
+                                const int n0 = bn + wc * 64 + nl;
+                                if (n0 < 2 * e.rope_dim) {
+                                    const bool is_k = n0 >= e.rope_dim;
+                                    const int d = n0 & 63;
+                                    const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
+                                    const float4 sn = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
+                                    const float o0 = v[0] * c.x - v[1] * sn.x, o1 = v[1] * c.y + v[0] * sn.y;
+                                    const float o2 = v[2] * c.z - v[3] * sn.z, o3 = v[3] * c.w + v[2] * sn.w;
+                                    v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                                }
+                                }
+                            }
+                            const int chunk = (nl >> 3) ^ (lr & 7);
+                            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            *(bf16x4*)(stg + lr * 128 + chunk * 16 + (nl & 4) * 2) = pk;
+                        }
+                }
+                // the same wave reads its region back: LDS ops of one wave execute in order, no barrier needed
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int lr = q * 8 + (lane >> 3);
+                    const int ch = lane & 7;
+                    const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
+                    const int m = bm + g * 128 + ps * 32 + lr;
+                    const int n0 = bn + wc * 64 + ch * 8;
+                    if (m < M && n0 < e.n_store && !(e.dbg & 128)) {
+                        if (e.dbg & 1024) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
+                        else {   // streamed once, read by the next kernel from HBM anyway
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                            const u32x4 vv = {val.x, val.y, val.z, val.w};
+                            __builtin_nontemporal_store(vv, (u32x4*)((bf16*)C + (size_t)m * ldc + n0));
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
-                    f32x4& v = acc[mh][nh][mi][ni];
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
+                    const int m = bm + g * 128 + mh * 64 + mi * 16 + r16;
+                    if (m >= M) continue;
+                    const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = epi_act(v[j], e.act);
-                    }
-                    if (MODE == MODE_GATE_STORE) { v[0] *= gt.x; v[1] *= gt.y; v[2] *= gt.z; v[3] *= gt.w; }
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const f32x4 v = acc[mh][nh][mi][ni];
+                            const int n0 = bn + wc * 64 + nh * 32 + ni * 16 + cq * 4;
+                            EpiArgs e2 = e; e2.bias = nullptr;                   // bias is already in the accumulators
+                            if constexpr (MODE == MODE_GATE_STORE) store4<To>(C + (size_t)m * ldc + n0, v[0], v[1], v[2], v[3]);
+                            else epi_store<MODE, To>(e2, C, ldc, m, pos, n0, v[0], v[1], v[2], v[3]);
+                        }
                 }
         }
-    if constexpr (sizeof(To) == 2 && MODE != MODE_GATE_RES) {
-        // bf16 output: transpose through the (now idle) LDS so that global stores are whole 128-byte rows.
-        // Wave-private 16 KiB region: 128 tokens x 64 features, 16-byte chunk index XOR (row & 7).
-        char* stg = smem + wave * 16384;
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = mh * 64 + mi * 16 + r16;
-                const int m = bm + g * 128 + row;
-                const int pos = (MODE == MODE_QKV_ROPE) ? (min(m, M - 1) % e.seq_n) : 0;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        f32x4 v = acc[mh][nh][mi][ni];
-                        const int nl = nh * 32 + ni * 16 + cq * 4;               // feature inside the wave's 64
-                        if constexpr (MODE == MODE_QKV_ROPE) {
-                            const int n0 = bn + wc * 64 + nl;
-                            if (n0 < 2 * e.rope_dim) {
-                                const bool is_k = n0 >= e.rope_dim;
-                                const int d = n0 & 63;
-                                const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
-                                const float4 s = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
-                                const float o0 = v[0] * c.x - v[1] * s.x, o1 = v[1] * c.y + v[0] * s.y;
-                                const float o2 = v[2] * c.z - v[3] * s.z, o3 = v[3] * c.w + v[2] * s.w;
-                                v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
-                            }
-                        }
-                        const int chunk = (nl >> 3) ^ (row & 7);
-                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *(bf16x4*)(stg + row * 128 + chunk * 16 + (nl & 4) * 2) = pk;
-                    }
-            }
-        // same wave reads its own region back: no barrier, the compiler's lgkmcnt wait orders it
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int ch = lane & 7;
-            const uint4 val = *(const uint4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-            const int m = bm + g * 128 + row;
-            const int n0 = bn + wc * 64 + ch * 8;
-            if (m < M && n0 < e.n_store && !((e.dbg & 128) && m != 0x7fffffff)) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
-        }
-    } else {
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = bm + g * 128 + mh * 64 + mi * 16 + r16;
-                if (m >= M || ((e.dbg & 128) && m != 0x7fffffff)) continue;
-                const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const f32x4 v = acc[mh][nh][mi][ni];
-                        const int n0 = bn + wc * 64 + nh * 32 + ni * 16 + cq * 4;
-                        if constexpr (MODE == MODE_GATE_STORE) store4<To>(C + (size_t)m * ldc + n0, v[0], v[1], v[2], v[3]);
-                        else epi_store<MODE, To>(e, C, ldc, m, pos, n0, v[0], v[1], v[2], v[3]);
-                    }
-            }
     }
+    if (g == 0) bar();                                         // balance group 1's extra barrier
+    VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
 }
 
 template <int MODE, typename To>
 hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                      hipStream_t st) {
-    constexpr int LDS = 2 * 4 * 128 * 128;
+    constexpr int LDS = 2 * 4 * 128 * 128 + 8 * 4096;          // 160 KiB: the whole CU
     static bool attr_set = false;
+    static int n_cu = 256;
     auto kern = gemm_pp_kernel<MODE, To>;
     if (!attr_set) {
         hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (he != hipSuccess) return he;
+        int dev = 0; hipGetDevice(&dev);
+        hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) n_cu = pr.multiProcessorCount / 8 * 8;
         attr_set = true;
     }
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
-    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    const int total = m_tiles * n_tiles;
+    const int grid = std::min(n_cu, (total + 7) / 8 * 8);      // one persistent workgroup per CU, a multiple of the 8 XCD labels
     kern<<<grid, 512, LDS, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
     return hipGetLastError();
 }
@@ -558,7 +624,7 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
     const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
     if constexpr (sizeof(T) == 2) {
         // bf16 throughput path: ping-pong kernel (byte offsets are 32-bit: operands must stay below 4 GiB)
-        if (big && !(e.dbg & 12) && K >= 128 && (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldw * 2 < ((size_t)1 << 32))
+        if (big && !(e.dbg & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldw * 2 < ((size_t)1 << 32))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
     if (big && (e.dbg & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
@@ -581,6 +647,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (g->tile != 0 && g->tile != 128 && g->tile != 256) { *err = "gemm: tile must be 0 (auto), 128 or 256"; return -22; }
     if (g->tile == 256 && g->N % 256) { *err = "gemm: the 256 tile needs N % 256 == 0"; return -22; }
     EpiArgs e;
+    e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.rope_dim = g->rope_dim;

@@ -37,3 +37,4 @@ int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err);
 int vvk_silu(float* x, size_t n, hipStream_t st, const char** err);
 int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err);
+int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err);

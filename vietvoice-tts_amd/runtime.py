@@ -49,7 +49,8 @@ class vv_gemm_args(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("cos_q", C.c_void_p), ("sin_q", C.c_void_p),
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
-                ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32), ("tile", C.c_int32)]
+                ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
+                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32)]
 
 
 class vv_attn_args(C.Structure):
@@ -103,6 +104,7 @@ EXPORTS = {
     "vv_conv_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "vv_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vv_rope_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
 }
 

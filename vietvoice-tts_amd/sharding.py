@@ -1,0 +1,55 @@
+"""Data-parallel plumbing for one node: which rank synthesises which unit, and how the model gets there.
+
+The hot path has no cross-rank dependence: each (reference clip, text chunk) unit is
+synthesised independently; only the host-side cross-fade couples chunks of one text.  So a job on N
+GPUs = one process per GPU, ONE collective at start-up (broadcast of the flat weight buffer, RCCL
+over xGMI on GPUs / gloo in the CPU tests), then each rank works through its own shard.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import pack
+from .model_spec import ModelSpec
+
+
+def shard_units(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time assignment of unit indices to ranks.  cost ~ N * (8 D^2 + 2 N D) per
+    unit (frames N); equal-cost units degrade to round-robin.  Every unit appears exactly once."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += costs[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def unit_cost(frames: int, dim: int = 1024) -> float:
+    return float(frames) * (8.0 * dim * dim + 2.0 * frames * dim)
+
+
+def broadcast_weights(spec: ModelSpec, acoustic_dtype: torch.dtype, weights: Optional[Dict[str, torch.Tensor]],
+                      device: torch.device, src: int = 0) -> Tuple[torch.Tensor, list]:
+    """Collective C1.  Rank `src` packs the fp32 weights into the flat device layout; every rank
+    allocates the same number of bytes (the layout is a function of shapes only) and receives it with
+    ONE broadcast.  Returns (flat uint8 tensor on `device`, [(name, offset, nbytes)])."""
+    import torch.distributed as dist
+    table, total = pack.plan(spec, acoustic_dtype)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        if weights is None:
+            raise ValueError("the source rank needs the weights")
+        cpu = torch.zeros(total, dtype=torch.uint8)
+        pack.fill(spec, acoustic_dtype, weights, cpu)
+        flat = cpu.to(device)
+    else:
+        flat = torch.empty(total, dtype=torch.uint8, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat, table
