@@ -65,8 +65,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
-    // transposed-read lane constants: 16-lane group g reads a 4-key x 16-d block
+    // transposed-read lane constants: 16-lane group g reads a 4-key x 16-d block.  Per d-tile the byte offset of this
+    // lane's 8-byte piece inside a 16-key slab is a constant; (key block, k-step, +8 rows) are immediates.
     const int tr_grp = (lane >> 4) & 1, tr_i = lane & 15, tr_q = tr_i >> 2, tr_p = tr_i & 3;
+    int tr_off[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int c = dt * 4 + 2 * tr_grp + (tr_p >> 1);
+        tr_off[dt] = (4 * h + tr_q) * 128 + ((c ^ (((tr_q >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
+    }
 
     const int n_tiles = (kv_len + 63) / 64;
     stage(0, 0);
@@ -107,39 +114,46 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2((m_run - m_new) * LOG2E);
-        m_run = m_new;
-        const float msc = m_new * LOG2E;
-        float psum = 0.f;
+        // rescale only when some row's running max grew (wave-uniform branch); alpha == 1 otherwise, so skipping is exact
+        if (__any(m_new > m_run)) {
+            const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        // p = 2^(s*log2e - m*log2e), two lanes of math per instruction (v_pk_fma_f32 / v_pk_add_f32)
+        const f32x2 msc2 = {-m_run * LOG2E, -m_run * LOG2E};
+        const f32x2 l2e2 = {LOG2E, LOG2E};
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(s[kb][r], LOG2E, -msc));
-                psum += p;
-                s[kb][r] = p;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 a = {s[kb][r], s[kb][r + 1]};
+                a = a * l2e2 + msc2;
+                a[0] = fast_exp2(a[0]);
+                a[1] = fast_exp2(a[1]);
+                ps2 += a;
+                s[kb][r] = a[0];
+                s[kb][r + 1] = a[1];
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        l_run += ps2[0] + ps2[1];
 
         // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[kb][8 * st + j];
-                const int key0 = kb * 32 + 16 * st + 4 * h;
+                const f32x8 pv = {s[kb][8 * st + 0], s[kb][8 * st + 1], s[kb][8 * st + 2], s[kb][8 * st + 3],
+                                  s[kb][8 * st + 4], s[kb][8 * st + 5], s[kb][8 * st + 6], s[kb][8 * st + 7]};
+                const bf16x8 pf = __builtin_convertvector(pv, bf16x8);       // 4 x v_cvt_pk_bf16_f32
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int c = dt * 4 + 2 * tr_grp + (tr_p >> 1);
-                    const int row0 = key0 + tr_q, row1 = row0 + 8;
-                    const char* a0 = sV + row0 * 128 + ((c ^ (((row0 >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
-                    const char* a1 = sV + row1 * 128 + ((c ^ (((row1 >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
+                    const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
+                    const char* a1 = a0 + 8 * 128;
                     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
                     const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
                     const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

@@ -18,19 +18,19 @@
 namespace {
 
 constexpr int VT = 256;       // time steps per workgroup
-constexpr int VR = 64;        // rows per workgroup
-constexpr int VCI = 8;        // input channels per K chunk
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
 
-// KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).
-template <int KW, bool TRANSPOSED>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt /*[Cin_pad][KW][rows_pad]*/,
+// KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).  VCI: input channels per K chunk.
+// RT: 32-row MFMA tiles per wave (2 -> 64 rows per workgroup, 1 -> 32 rows for the narrow last stage).
+template <int KW, bool TRANSPOSED, int VCI, int RT>
+__global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wt /*[Cin_pad][KW][rows_pad]*/,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            const float* __restrict__ resid, int Cin, int rows_total,
                                                            int rows_pad, int T_in, int T_out, int Cout, int dil, int up,
                                                            float pre_slope, float out_scale, int accumulate,
                                                            const int* __restrict__ len_in) {
+    constexpr int VR = RT * 32;
     // halo: conv reads time + kw*dil - left; transposed reads q and q-1
     const int left = TRANSPOSED ? 1 : dil * (KW - 1) / 2;
     const int span = TRANSPOSED ? 1 : dil * (KW - 1);
@@ -49,14 +49,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
     const int lin = len_in ? min(len_in[b], T_in) : T_in;
     const float* inb = in + (size_t)b * Cin * T_in;
 
-    f32x16 acc[2][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Latency hiding is by occupancy (3-4 workgroups per CU at ~100 VGPRs): a register-prefetch pipeline
+    // was measured slower here because its staging maps halve the occupancy.
     for (int c0 = 0; c0 < Cin; c0 += VCI) {
         __syncthreads();
         // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 + i - left])
@@ -75,18 +77,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < VCI / 2; ++j) {
-            const int c = 2 * j + h;
+            const int c = 2 * j + h;                   // lane half h takes channel 2j + h
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
                 const int off = TRANSPOSED ? (left - kw) : kw * dil;          // window index = local time + off
-                float a[2], x[2];
+                float a[RT], x[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = ws[(c * KW + kw) * VR + i * 32 + r32];
-                    x[i] = xs[c * xw_pad + wave * 64 + i * 32 + r32 + off];
-                }
+                for (int i = 0; i < RT; ++i) a[i] = ws[(c * KW + kw) * VR + i * 32 + r32];
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri)
+                for (int i = 0; i < 2; ++i) x[i] = xs[c * xw_pad + wave * 64 + i * 32 + r32 + off];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
                     for (int ti = 0; ti < 2; ++ti)
                         acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], x[ti], acc[ri][ti], 0, 0, 0);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restri
     float* outb = out + (size_t)b * Cout * T_out;
     const float* resb = resid ? resid + (size_t)b * Cout * T_out : nullptr;
 #pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
+    for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int q = q0 + wave * 64 + ti * 32 + r32;
@@ -197,35 +198,41 @@ __global__ __launch_bounds__(256) void mel_slice_kernel(const float* __restrict_
     }
 }
 
-template <int KW, bool TR>
-int launch_conv(const vv_conv_args* a, hipStream_t st) {
+template <int KW, bool TR, int VCI, int RT>
+int launch_conv_t(const vv_conv_args* a, hipStream_t st) {
+    constexpr int VR = RT * 32;
     const int span = TR ? 1 : a->dil * (KW - 1);
     const int xw_pad = (VT + span + 3) & ~3;
     const size_t lds = (size_t)(VCI * xw_pad + VCI * KW * VR) * sizeof(float);
     const int q_total = TR ? a->T_in + 1 : a->T_out;
-    dim3 grid((q_total + VT - 1) / VT, a->rows_pad / VR, a->B);
-    conv_mfma_kernel<KW, TR><<<grid, 256, lds, st>>>(a->in, a->W, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad,
-                                                    a->T_in, a->T_out, a->Cout, a->dil, a->up, a->pre_slope, a->out_scale,
-                                                    a->accumulate, a->len_in);
+    dim3 grid((q_total + VT - 1) / VT, (a->rows_total + VR - 1) / VR, a->B);
+    conv_mfma_kernel<KW, TR, VCI, RT><<<grid, 256, lds, st>>>(a->in, a->W, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad,
+                                                             a->T_in, a->T_out, a->Cout, a->dil, a->up, a->pre_slope, a->out_scale,
+                                                             a->accumulate, a->len_in);
     return 0;
+}
+template <int KW, bool TR, int VCI>
+int launch_conv(const vv_conv_args* a, hipStream_t st) {
+    if (a->rows_total <= 32) return launch_conv_t<KW, TR, VCI, 1>(a, st);      // narrow stage: no zero-padded MFMA rows
+    return launch_conv_t<KW, TR, VCI, 2>(a, st);
 }
 
 }  // namespace
 
 int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->T_in <= 0 || a->T_out <= 0) { *err = "conv: empty shape"; return -22; }
-    if (a->rows_pad % VR || a->rows_pad < a->rows_total || ((uintptr_t)a->W % 16)) { *err = "conv: weight slab must be padded to 64 rows and 16-byte aligned"; return -22; }
+    if (a->rows_pad % 64 || a->rows_pad < a->rows_total || ((uintptr_t)a->W % 16)) { *err = "conv: weight slab must be padded to 64 rows and 16-byte aligned"; return -22; }
     if (a->transposed) {
         if (a->KW != 2 || a->up < 2 || (a->up & 1) || a->rows_total != a->Cout * a->up || a->T_out != a->T_in * a->up) {
             *err = "conv: transposed form needs kernel = 2*stride, even stride"; return -22;
         }
-        launch_conv<2, true>(a, st);
+        launch_conv<2, true, 16>(a, st);
     } else {
-        if (a->rows_total != a->Cout || a->T_out != a->T_in || a->dil < 1 || a->dil * (a->KW - 1) > 64) { *err = "conv: bad conv shape"; return -22; }
+        if (a->rows_total != a->Cout || a->T_out != a->T_in || a->dil < 1 || a->dil > 5) { *err = "conv: bad conv shape (dilation 1..5)"; return -22; }
         switch (a->KW) {
-            case 3: launch_conv<3, false>(a, st); break;
-            case 7: launch_conv<7, false>(a, st); break;
-            case 11: launch_conv<11, false>(a, st); break;
+            case 3: launch_conv<3, false, 16>(a, st); break;
+            case 7: launch_conv<7, false, 8>(a, st); break;
+            case 11: launch_conv<11, false, 8>(a, st); break;
             default: *err = "conv: kernel width must be 3, 7 or 11"; return -22;
         }
     }
