@@ -64,6 +64,68 @@ def make_inputs(spec: ModelSpec, B: int, rank: int, device):
     return d, N
 
 
+def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, device):
+    """BASELINE configs[3]: 32*world units, text 64-512 tokens, reference clips 3-9 s, LPT-sharded by frame cost;
+    this rank's shard becomes one ragged batch (per-item lengths on the device, masks in every kernel)."""
+    g = torch.Generator().manual_seed(SEED + 77)
+    total = per_rank * world
+    toks = torch.randint(64, 513, (total,), generator=g)
+    secs = 3.0 + 6.0 * torch.rand(total, generator=g)
+    samples = (secs * spec.sample_rate).to(torch.int64) // 256 * 256
+    ref_frames = samples // spec.hop_length + 1
+    gen_frames = torch.clamp((toks.float() * 0.62 * 6.48).to(torch.int64), min=94)     # ~62 % of the ids are target text
+    gen_frames = torch.minimum(gen_frames, 1875 - ref_frames)                            # 20 s chunk cap of the reference
+    frames = (ref_frames + gen_frames).tolist()
+    mine = sharding.shard_units([sharding.unit_cost(f, spec.dim) for f in frames], world)[rank]
+    B = len(mine)
+    S, T = int(samples[mine].max()), int(toks[mine].max())
+    audio = torch.zeros(B, S, dtype=torch.int16)
+    ids = torch.zeros(B, T, dtype=torch.int32)
+    for j, u in enumerate(mine):
+        audio[j, : int(samples[u])] = synth_reference_clip(1000 + u, int(samples[u]))
+        ids[j, : int(toks[u])] = torch.randint(1, spec.vocab_size, (int(toks[u]),), generator=g, dtype=torch.int32)
+    seq = torch.tensor([frames[u] for u in mine], dtype=torch.int32)
+    N = int(seq.max())
+    noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
+    d = dict(audio=audio.to(device), audio_len=samples[mine].to(torch.int32).to(device), ids=ids.to(device),
+             text_len=toks[mine].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
+    t_gen_max = int(gen_frames[mine].max())
+    audio_s = float(gen_frames[mine].sum()) * spec.hop_length / spec.sample_rate
+    return d, N, t_gen_max, audio_s, B
+
+
+def longform(a):
+    """BASELINE configs[4]: one 4096-character text through the drop-in TTSEngine (chunking, ragged GPU batches of 8
+    chunks, hipGraph-replayed vocoder step, host cross-fade).  Wall clock includes all host plumbing."""
+    import tempfile
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    sent = "Hôm nay trời đẹp quá, chúng ta cùng nhau đi dạo quanh hồ và ngắm hoa nở bên đường nhé. "
+    text = (sent * 60)[:4096]
+    with tempfile.TemporaryDirectory() as d:
+        cfg = ModelConfig(model_cache_dir=d, synthetic_model=True, model_spec=a.spec, acoustic_dtype=a.dtype, nfe_step=a.nfe,
+                          max_batch_chunks=8, use_hip_graph=True)
+        eng = TTSEngine(cfg)
+        for _ in range(a.warmup):
+            eng.synthesize(text)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tot = 0
+        for _ in range(a.steps):
+            wave, _secs = eng.synthesize(text)
+            tot += wave.size
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        chunks = len(eng._last_plan) if hasattr(eng, "_last_plan") else None
+        eng.cleanup()
+    audio_s = tot / 24000.0
+    print(json.dumps({"metric": "audio-seconds/sec (24 kHz), long-form 4k-char text, 8 chunks in flight (BASELINE configs[4])",
+                      "value": round(audio_s / el, 3), "unit": "audio-seconds/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                      "ms_per_step": round(el / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": a.dtype, "data": "synthetic voice pack + random-init weights",
+                      "config": {"workload": "longform: 4096 chars, chunked by the reference rule, max_batch_chunks=8, hipGraph vocoder",
+                                 "chunks": chunks, "spec": a.spec}}), flush=True)
+
+
 def cpu_baseline(spec, weights, nfe_step):
     """Oracle (kind 'port') on the host cores, bounded sample, rank 0 only."""
     from oracle.vv_oracle import Oracle
@@ -106,7 +168,12 @@ def main():
     ap.add_argument("--nfe", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spec", default="full", choices=["full", "small", "tiny"])
+    ap.add_argument("--workload", default="batch32", choices=["batch32", "mixed256", "longform"],
+                    help="batch32 = the headline metric (BASELINE configs[2]); mixed256 = configs[3] (32 ragged units per GPU); "
+                         "longform = configs[4] (4k-char text through TTSEngine, 8 chunks in flight, hipGraph vocoder)")
     a = ap.parse_args()
+    if a.workload == "longform":
+        return longform(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,10 +201,14 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
-    d, N = make_inputs(spec, a.batch, rank, device)
+    if a.workload == "mixed256":
+        d, N, t_gen, audio_s_rank, nb = make_mixed_inputs(spec, a.batch, rank, world, device)
+    else:
+        d, N = make_inputs(spec, a.batch, rank, device)
+        t_gen, audio_s_rank, nb = GEN_FRAMES, a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch
 
     def step():
-        return eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], GEN_FRAMES)
+        return eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen)
 
     for _ in range(a.warmup):
         step()
@@ -156,8 +227,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     pcm_len = out[2]
-    audio_s_per_utt = float(pcm_len[0].item()) / spec.sample_rate
-    assert int(pcm_len.min().item()) == GEN_FRAMES * spec.hop_length
+    assert abs(float(pcm_len.sum().item()) / spec.sample_rate - audio_s_rank) < 1e-3
+    if dist is not None:                                  # total audio over all ranks (ragged shards differ)
+        ta = torch.tensor([audio_s_rank], dtype=torch.float64, device=device)
+        dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+        audio_s_all = float(ta.item())
+    else:
+        audio_s_all = audio_s_rank
 
     if rank != 0:
         if dist is not None:
@@ -182,15 +258,17 @@ def main():
             classes[k] = {"ms": round(v["ms"], 2), "launches": v["launches"],
                           "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                           "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
-    total_audio = world * a.batch * a.steps * audio_s_per_utt
+    total_audio = audio_s_all * a.steps
     res = {
         "metric": "audio-seconds/sec (24 kHz) at batch 32, 256-token utterances; RTF",
         "value": round(total_audio / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic (seeded utterances and random-init weights; no checkpoint offline)",
         "rtf": round(elapsed / total_audio, 6),
-        "config": {"workload": f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
-                               f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
+        "config": {"workload": (f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
+                                if a.workload == "batch32" else
+                                f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips, N_max={N}), ")
+                               + f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
         "roofline": roofline, "kernel_classes": classes,
     }

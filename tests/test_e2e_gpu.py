@@ -136,3 +136,21 @@ def test_batch_equals_singles(hip_tiny, tiny_setup):
         assert int(lenb[b]) == n
         assert float((xb[b, :sl] - xs[0]).abs().max()) < 5e-5 * float(xs[0].abs().max()) + 1e-6
         assert int((pcmb[b, :n].int() - pcms[0, :n].int()).abs().max()) <= 1
+
+
+def test_graph_captured_decode_matches_eager(hip_tiny, tiny_setup):
+    """Config 5: the vocoder step captured into a hipGraph replays bit-exactly for new inputs."""
+    spec, _, _ = tiny_setup
+    eng = hip_tiny["f32"]
+    batch = make_batch(spec, [256 * 16, 256 * 16], [20, 14], [12, 9], seed=21)
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"])
+    x = d["noise"].clone()
+    eng.transformer_steps(x, pre, 0, 3)
+    graphed = eng.capture_decode(2, d["N"], d["t_gen_max"])
+    for scale in (1.0, 0.5):
+        xin = x * scale
+        pcm_e, len_e = eng.decode(xin, pre, d["t_gen_max"])
+        pcm_g, len_g = graphed(xin, pre["ref_signal_len"], pre["seq_len"])
+        torch.cuda.synchronize()
+        assert torch.equal(len_e, len_g) and torch.equal(pcm_e, pcm_g)

@@ -58,6 +58,7 @@ class ModelConfig:
     synthetic_model: bool = False           # build a seeded synthetic model pack when none is cached
     model_spec: str = "full"                # architecture preset of a synthetic pack: full | small | tiny
     max_batch_chunks: int = 32              # chunks of one long text synthesised per GPU batch
+    use_hip_graph: bool = False             # replay the vocoder step from a captured hipGraph (fixed frame buckets)
 
     def __post_init__(self):
         if not 0.1 <= self.speed <= 5.0:

@@ -43,6 +43,8 @@ class TTSEngine:
         self.audio_processor = AudioProcessor()
         self.sample_cache = {}
         self._lock = threading.Lock()
+        self._decode_graphs = {}
+        self._last_plan = []
 
     def cleanup(self) -> None:
         if self.model_session_manager:
@@ -150,8 +152,22 @@ class TTSEngine:
             for i in range(B):
                 noise[i, : seq[i]] = torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32)
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-            _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]),
-                                                         t32(seq), N, noise.to(dev), int(seq.max()) - ref_frames)
+            t_gen = int(seq.max()) - ref_frames
+            if self.config.use_hip_graph:
+                # fixed frame buckets (multiples of 128) so that one captured vocoder graph serves every chunk group
+                Nb = (N + 127) // 128 * 128
+                noise_b = torch.zeros((B, Nb, spec.n_mel), dtype=torch.float32)
+                noise_b[:, :N] = noise
+                pre = eng.preprocess(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]), t32(seq), Nb)
+                x = noise_b.to(dev)
+                eng.transformer_steps(x, pre, 0, eng.n_steps)
+                key = (B, Nb, Nb - ref_frames)
+                if key not in self._decode_graphs:
+                    self._decode_graphs[key] = eng.capture_decode(*key)
+                pcm, pcm_len = self._decode_graphs[key](x, pre["ref_signal_len"], pre["seq_len"])
+            else:
+                _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]),
+                                                             t32(seq), N, noise.to(dev), t_gen)
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
             for i in range(B):
                 waves.append(pcm[i, : pcm_len[i]].reshape(1, 1, -1))
@@ -168,6 +184,7 @@ class TTSEngine:
         try:
             with self._lock:
                 inputs_list = self._prepare_inputs(ref_audio, ref_text, text, speed=speed)
+                self._last_plan = [int(i[2][0]) for i in inputs_list]
                 if self.model_session_manager.engine is not None:
                     waves = self._synthesize_device(inputs_list)
                 else:

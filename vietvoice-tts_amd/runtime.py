@@ -290,6 +290,12 @@ class HipSynth:
         pcm, pcm_len = self.decode(x, pre, t_gen_max)
         return x, pcm, pcm_len, pre
 
+    # ------------------------------------------------------------------ hipGraph-captured vocoder step (config 5)
+    def capture_decode(self, B: int, N: int, t_gen_max: int) -> "GraphedDecode":
+        """Capture the decode stage (frame slice -> vocoder -> int16) for a fixed shape into a hipGraph.
+        Long-form synthesis replays it per chunk group: ~80 launches become one graph launch."""
+        return GraphedDecode(self, B, N, t_gen_max)
+
     # ------------------------------------------------------------------ profiling
     def prof_enable(self, on: bool):
         self._check(self.lib.vv_prof_enable(self.ctx, 1 if on else 0))
@@ -300,3 +306,36 @@ class HipSynth:
         self._check(self.lib.vv_prof_collect(self.ctx, la, ms, fl, by))
         return {PROF_CLASSES[i]: {"launches": int(la[i]), "ms": float(ms[i]), "flops": float(fl[i]), "bytes": float(by[i])}
                 for i in range(n)}
+
+
+class GraphedDecode:
+    """hipGraph replay of ``HipSynth.decode`` at a fixed (B, N, t_gen_max).  Static input buffers are
+    owned here; ``__call__`` copies the state in and replays.  The workspace is sized by a warm-up call
+    before capture (no allocation may happen inside a captured region)."""
+
+    def __init__(self, eng: HipSynth, B: int, N: int, t_gen_max: int):
+        self.eng, self.B, self.N, self.t_gen_max = eng, B, N, t_gen_max
+        dev, s = eng.device, eng.spec
+        self.x = torch.zeros((B, N, s.n_mel), dtype=torch.float32, device=dev)
+        self.ref_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.seq_len = torch.full((B,), N, dtype=torch.int32, device=dev)
+        self.pcm = torch.zeros((B, t_gen_max * s.hop_length), dtype=torch.int16, device=dev)
+        self.pcm_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._launch()                                   # warm-up: sizes the workspace, sets kernel attributes
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._launch()
+
+    def _launch(self):
+        e = self.eng
+        with e._lock, torch.cuda.device(e.device):
+            e._check(e.lib.vv_decode(e.ctx, self.B, self.N, self.x.data_ptr(), self.ref_len.data_ptr(), self.seq_len.data_ptr(),
+                                     self.t_gen_max, self.pcm.data_ptr(), self.pcm.shape[1], self.pcm_len.data_ptr(), None, e._stream()))
+
+    def __call__(self, x: torch.Tensor, ref_len: torch.Tensor, seq_len: torch.Tensor):
+        self.x.copy_(x)
+        self.ref_len.copy_(ref_len)
+        self.seq_len.copy_(seq_len)
+        self.graph.replay()
+        return self.pcm, self.pcm_len
