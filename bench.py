@@ -252,6 +252,18 @@ def main():
     roofline = {"bound": "mfma", "kernel": "gemm_kernel (K6, %s MFMA)" % a.dtype, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4)}
+    def _rf(name, bound, peak):
+        v = prof[name]
+        if not v["launches"] or v["ms"] <= 0:
+            return None
+        ach = (v["flops"] / 1e12 if bound == "mfma" else v["bytes"] / 1e9) / (v["ms"] * 1e-3)
+        return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": round(ach / peak, 4), "launches": v["launches"]}
+    other_rooflines = {"attention (K8, bf16 MFMA)": _rf("attention", "mfma", peak),
+                       "layernorm+residual (K4)": _rf("norm", "hbm", HBM_PEAK_GBS),
+                       "pos-conv (K3, bf16 MFMA)": _rf("posconv", "mfma", peak),
+                       "vocoder convs (K11/K12, f32 MFMA)": _rf("voc_conv", "mfma", MFMA_F32_PEAK_TFLOPS),
+                       "vocoder conv_post+tanh+int16 (K13)": _rf("voc_post", "hbm", HBM_PEAK_GBS)}
     classes = {}
     for k, v in prof.items():
         if v["launches"]:
@@ -270,7 +282,7 @@ def main():
                                 f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips, N_max={N}), ")
                                + f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
-        "roofline": roofline, "kernel_classes": classes,
+        "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
     }
     if bcast_ms is not None:
         res["weight_pack_and_broadcast_ms"] = round(bcast_ms, 2)

@@ -174,6 +174,9 @@ int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16
                  int B, int C, int T, int KW, float pre_slope, const int32_t* len_in, void* stream);
 int vv_mel(vv_ctx* ctx, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max,
            void* stream);
+/* K5 GroupNorm over channel-major [B][C][T] fp32 (G groups), optional per-channel affine and fused activation code */
+int vv_groupnorm(vv_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G,
+                 float eps, int act, void* stream);
 /* out[pos][2i] = cos[pos][2i], out[pos][2i+1] = sin[pos][2i]  (tables with duplicated pairs, n rows x 64) */
 int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
 int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);

@@ -412,3 +412,19 @@ def test_cfg_euler(hip_tiny):
     gu.check(eng, eng.lib.vv_cfg_euler(eng.ctx, dx.data_ptr(), dp.data_ptr(), ldp, BN, M, 2.0, 0.03, gu.stream()))
     torch.cuda.synchronize()
     assert gu.rel_err(dx, ref) < 1e-6
+
+
+@pytest.mark.parametrize("B,Cc,T,G", [(2, 64, 300, 8), (1, 32, 4097, 32), (3, 48, 50, 1)])
+def test_groupnorm(hip_tiny, B, Cc, T, G):
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(B * 100 + G)
+    x = torch.randn(B, Cc, T, generator=g) * 3 + 1.5
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    y = torch.zeros(B, Cc, T, device=gu.DEV)
+    dx, dg, db = x.to(gu.DEV), gamma.to(gu.DEV), beta.to(gu.DEV)
+    for act, fn in ((0, lambda v: v), (4, F.mish)):
+        gu.check(eng, eng.lib.vv_groupnorm(eng.ctx, dx.data_ptr(), y.data_ptr(), dg.data_ptr(), db.data_ptr(), B, Cc, T, G, 1e-5, act, gu.stream()))
+        torch.cuda.synchronize()
+        ref = fn(F.group_norm(x, G, gamma, beta, eps=1e-5))
+        assert gu.rel_err(y, ref) < 1e-5

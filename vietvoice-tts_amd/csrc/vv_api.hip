@@ -596,6 +596,9 @@ int vv_mel(vv_ctx* c, const int16_t* audio, int ld_audio, const int32_t* audio_l
     SINGLE(c, vvk_mel(audio, ld_audio, audio_len, c->Wf("const.window"), c->Wf("const.tw_cos"), c->Wf("const.tw_sin"), c->Wf("const.mel_fb"),
                       mel, B, F_max, c->cfg.n_fft, c->cfg.hop_length, c->cfg.n_mel, (hipStream_t)st, &m__));
 }
+int vv_groupnorm(vv_ctx* c, const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act, void* st) {
+    SINGLE(c, vvk_groupnorm(x, y, gamma, beta, B, C, T, G, eps, act, (hipStream_t)st, &m__));
+}
 int vv_rope_compact(vv_ctx* c, const float* cos_t, const float* sin_t, float* out, int n, void* st) {
     SINGLE(c, vvk_rope_compact(cos_t, sin_t, out, n, (hipStream_t)st, &m__));
 }

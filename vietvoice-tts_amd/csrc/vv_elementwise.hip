@@ -247,6 +247,41 @@ __global__ void dup_len_kernel(const int* __restrict__ seq_len, int* __restrict_
     if (b < B) { out[b] = seq_len[b]; out[B + b] = seq_len[b]; }
 }
 
+// ---------------------------------------------------------------- K5: GroupNorm, channel-major [B][C][T]
+// One workgroup per (batch item, group): the group's C/G x T slab is contiguous.  Two streaming passes
+// (sum / sum of squared deviations -> numerically the two-pass form), wave-shuffle + LDS reductions, then
+// normalise with per-channel affine and an optional fused activation.  HBM-bound: 3 reads + 1 write per element
+// (the slab of a vocoder-sized group does not fit registers; L2 absorbs part of the re-reads).
+__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int C, int T, int G, float eps, int act) {
+    __shared__ float red[4];
+    __shared__ float stat[2];
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int cpg = C / G;
+    const size_t n = (size_t)cpg * T;
+    const float* xs = x + ((size_t)b * C + (size_t)g * cpg) * T;
+    float* ys = y + ((size_t)b * C + (size_t)g * cpg) * T;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) s += xs[i];
+    const float mean = block_sum(s) / (float)n;
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) { const float d = xs[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(block_sum(q) / (float)n + eps);
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const int c = g * cpg + (int)(i / T);
+        const float v = (xs[i] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+        ys[i] = act_apply(v, act);
+    }
+}
+
 __global__ __launch_bounds__(256) void rope_compact_kernel(const float* __restrict__ c, const float* __restrict__ s, float* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;      // one (pos, pair)
     if (i >= n * 32) return;
@@ -369,6 +404,14 @@ int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int
 }
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err) {
     dup_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(seq_len, out, B);
+    VVK_CHECK_LAUNCH();
+    return 0;
+}
+int vvk_groupnorm(const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act,
+                  hipStream_t st, const char** err) {
+    if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G) { *err = "groupnorm: C must be a multiple of G"; return -22; }
+    dim3 grid(G, B);
+    groupnorm_kernel<<<grid, 256, 0, st>>>(x, y, gamma, beta, C, T, G, eps, act);
     VVK_CHECK_LAUNCH();
     return 0;
 }

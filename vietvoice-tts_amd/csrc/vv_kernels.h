@@ -38,3 +38,5 @@ int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char*
 int vvk_silu(float* x, size_t n, hipStream_t st, const char** err);
 int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err);
 int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err);
+int vvk_groupnorm(const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act,
+                  hipStream_t st, const char** err);

@@ -121,57 +121,83 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
         }
 }
 
-// ---- K13: conv_post (C -> 1, k = KW) on lrelu(x), tanh, *32767, clip, truncate to int16
+// ---- K13: conv_post (C -> 1, k = KW) on lrelu(x), tanh, *32767, clip, truncate to int16.  HBM-bound:
+// 4*C bytes read + 2 written per sample.  The window [t0-4, t0+TP+4) of 8 channels is staged with ALIGNED
+// 16-byte loads (the conv's -3 offset would otherwise force 4-byte loads), activation applied once per element.
 template <int KW>
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ in, const float* __restrict__ w /*[C][KW]*/,
                                                         float bias, int16_t* __restrict__ pcm, int ld_pcm, float* __restrict__ wave_f32,
                                                         int C, int T, float pre_slope, const int* __restrict__ len_in) {
     constexpr int TP = 1024;                 // outputs per block (4 per thread)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = (float*)smem;                // [CH][TP + KW - 1] per channel chunk
     constexpr int CH = 8;
-    constexpr int XW = TP + KW - 1;
-    constexpr int XWP = (XW + 3) & ~3;
+    constexpr int XW4 = TP / 4 + 2;          // float4 per channel row: covers t0-4 .. t0+TP+3
+    constexpr int XWP = XW4 * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;                // [CH][XWP]
     float* wsm = xs + CH * XWP;              // [C][KW] (C <= 64)
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * TP;
     const int lin = len_in ? min(len_in[b], T) : T;
     const float* inb = in + (size_t)b * C * T;
+    const bool vec_ok = (T & 3) == 0;        // rows stay 16-byte aligned
     for (int i = threadIdx.x; i < C * KW; i += 256) wsm[i] = w[i];
     float acc[4] = {bias, bias, bias, bias};
     const int tl = threadIdx.x * 4;
     for (int c0 = 0; c0 < C; c0 += CH) {
         __syncthreads();
-        for (int i = threadIdx.x; i < CH * XW; i += 256) {
-            const int c = i / XW, k = i - c * XW;
-            const int pos = t0 + k - KW / 2;
-            float v = 0.f;
-            if (c0 + c < C && pos >= 0 && pos < lin) v = lrelu(inb[(size_t)(c0 + c) * T + pos], pre_slope);
-            xs[c * XWP + k] = v;
+        for (int i = threadIdx.x; i < CH * XW4; i += 256) {
+            const int c = i / XW4, k4 = i - c * XW4;
+            const int pos = t0 - 4 + k4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + c < C) {
+                const float* row = inb + (size_t)(c0 + c) * T;
+                if (vec_ok && pos >= 0 && pos + 3 < lin) {
+                    v = *(const float4*)(row + pos);
+                } else {
+                    if (pos + 0 >= 0 && pos + 0 < lin) v.x = row[pos + 0];
+                    if (pos + 1 >= 0 && pos + 1 < lin) v.y = row[pos + 1];
+                    if (pos + 2 >= 0 && pos + 2 < lin) v.z = row[pos + 2];
+                    if (pos + 3 >= 0 && pos + 3 < lin) v.w = row[pos + 3];
+                }
+            }
+            *(float4*)(xs + c * XWP + k4 * 4) = make_float4(lrelu(v.x, pre_slope), lrelu(v.y, pre_slope), lrelu(v.z, pre_slope), lrelu(v.w, pre_slope));
         }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if (c0 + c >= C) break;
-            float xv[KW + 3];
-#pragma unroll
-            for (int k = 0; k < KW + 3; ++k) xv[k] = xs[c * XWP + tl + k];
+            // outputs tl..tl+3 need window indices (tl + 4 - KW/2) .. (tl + 4 + 3 + KW/2): three aligned float4
+            const float4 a0 = *(const float4*)(xs + c * XWP + tl), a1 = *(const float4*)(xs + c * XWP + tl + 4),
+                         a2 = *(const float4*)(xs + c * XWP + tl + 8);
+            const float xv[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const float wk = wsm[(c0 + c) * KW + k];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, xv[o + k], acc[o]);
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, xv[o + k + 4 - KW / 2], acc[o]);
             }
         }
     }
+    short4 pk;
+    float4 wf;
+    float ys[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const int t = t0 + tl + o;
-        if (t >= T) break;
-        const float y = tanhf(acc[o]);
-        if (wave_f32) wave_f32[(size_t)b * T + t] = y;
-        const float s = fminf(fmaxf(y * 32767.0f, -32768.0f), 32767.0f);
-        pcm[(size_t)b * ld_pcm + t] = (int16_t)s;        // truncation toward zero, as an ONNX Cast does
+    for (int o = 0; o < 4; ++o) ys[o] = tanhf(acc[o]);
+    wf = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    pk.x = (short)fminf(fmaxf(ys[0] * 32767.0f, -32768.0f), 32767.0f);     // truncation toward zero, as an ONNX Cast does
+    pk.y = (short)fminf(fmaxf(ys[1] * 32767.0f, -32768.0f), 32767.0f);
+    pk.z = (short)fminf(fmaxf(ys[2] * 32767.0f, -32768.0f), 32767.0f);
+    pk.w = (short)fminf(fmaxf(ys[3] * 32767.0f, -32768.0f), 32767.0f);
+    const int t = t0 + tl;
+    if (t + 3 < T && (ld_pcm & 3) == 0 && vec_ok) {
+        *(short4*)(pcm + (size_t)b * ld_pcm + t) = pk;
+        if (wave_f32) *(float4*)(wave_f32 + (size_t)b * T + t) = wf;
+    } else {
+        const short ps[4] = {pk.x, pk.y, pk.z, pk.w};
+        for (int o = 0; o < 4 && t + o < T; ++o) {
+            pcm[(size_t)b * ld_pcm + t + o] = ps[o];
+            if (wave_f32) wave_f32[(size_t)b * T + t + o] = ys[o];
+        }
     }
 }
 
@@ -244,7 +270,7 @@ int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
 int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T, int KW,
                   float pre_slope, const int* len_in, hipStream_t st, const char** err) {
     if (KW != 7 || C > 64 || C < 1) { *err = "conv_post: k=7 and C<=64 expected"; return -22; }
-    const size_t lds = (size_t)(8 * ((1024 + 6 + 3) & ~3) + C * 7) * sizeof(float);
+    const size_t lds = (size_t)(8 * (1024 + 8) + C * 7) * sizeof(float);
     dim3 grid((T + 1023) / 1024, B);
     conv_post_kernel<7><<<grid, 256, lds, st>>>(in, w, bias, pcm, ld_pcm, wave_f32, C, T, pre_slope, len_in);
     hipError_t he = hipGetLastError();
