@@ -2,12 +2,12 @@
 // token-major activations [rows][D].  Per group this is an implicit GEMM with K = 31 * 64:
 //   out[t][co] = bias[co] + sum_kw sum_ci  W[g][kw][co][ci] * in[t + kw - pad][g*64 + ci]
 //
-// bf16: one workgroup = 128 tokens x 64 output channels of one (sequence, group).  The
-// (128 + 30)-token input window is staged ONCE in LDS (128-byte rows, swz128 image) with zero fill
+// bf16: one workgroup = 256 tokens x 64 output channels of one (sequence, group).  The
+// (256 + 30)-token input window is staged ONCE in LDS (128-byte rows, swz128 image) with zero fill
 // outside [0, len); every tap re-reads it at a row offset, so HBM sees each activation once.
-// Weight fragments (8 KiB per tap, shared by every workgroup of the group) come straight from
-// L2 into registers, software-prefetched one tap ahead.  MFMA v_mfma_f32_16x16x32_bf16 with the
-// transposed product (A = weights, B = tokens) so a lane owns 4 consecutive channels of a token.
+// The tap's 8 KiB weight tile is staged by LDS-DMA into a double buffer one tap ahead.  MFMA
+// v_mfma_f32_16x16x32_bf16 with the transposed product (A = weights, B = tokens) so a lane owns 4
+// consecutive channels of a token.
 //
 // fp32: exact-f32 VALU kernel for the numerics configuration (not the throughput path).
 #include "vv_common.h"
@@ -15,15 +15,21 @@
 
 namespace {
 
-constexpr int PC_TOK = 128;
+constexpr int PC_TOK = 256;
 
+// bf16: one workgroup = 256 tokens x 64 output channels of one (sequence, group), 8 waves x 32 tokens.
+// LDS: the (256 + KW - 1)-token input window (128-byte rows, swz128, zero fill outside [0, len)) staged once, plus a
+// double-buffered 8 KiB weight tile per tap filled by LDS-DMA one tap ahead -- the tap's weights are read from L2
+// once per workgroup instead of once per wave (the first version moved ~9 TB/s of L2->CU traffic that way).
 template <typename To>
-__global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16* __restrict__ in, int ldi,
+__global__ __launch_bounds__(512, 2) void posconv_bf16_kernel(const bf16* __restrict__ in, int ldi,
                                                               const bf16* __restrict__ W /*[G][KW][64co][64ci]*/,
                                                               const float* __restrict__ bias, To* __restrict__ out, int ldo,
                                                               const bf16* __restrict__ resid, int ldr, int seq_n,
                                                               const int* __restrict__ seq_len, int B, int KW) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // (PC_TOK + KW - 1) rows x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][64 x 128 B] weight taps | (PC_TOK + KW - 1) rows x 128 B
+    char* wbuf = smem;
+    char* xwin = smem + 2 * 8192;
     const int g = blockIdx.y, seq = blockIdx.z;
     const int t0 = blockIdx.x * PC_TOK;
     const int pad = KW / 2;
@@ -32,15 +38,20 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows = PC_TOK + KW - 1;
 
+    // weight tap kw -> LDS: 8 pieces of 8 rows x 128 B, one per wave; swizzle on the source address
+    const int wrow = wave * 8 + (lane >> 3);
+    const bf16* wsrc = W + (size_t)g * KW * 4096 + (size_t)wrow * 64 + (((lane & 7) ^ ((wrow >> 1) & 7)) * 8);
+    auto stage_w = [&](int kw, int buf) { glds16(wsrc + (size_t)kw * 4096, wbuf + buf * 8192 + wave * 1024); };
+    stage_w(0, 0);
+
     // ---- stage the window (register path: needs zero fill at the sequence edges)
-    for (int i = threadIdx.x; i < rows * 8; i += 256) {
+    for (int i = threadIdx.x; i < rows * 8; i += 512) {
         const int r = i >> 3, c = i & 7;
         const int t = t0 + r - pad;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (t >= 0 && t < len) v = *(const uint4*)(in + ((size_t)seq * seq_n + t) * ldi + g * 64 + c * 8);
-        *(uint4*)(smem + swz128(r, c)) = v;
+        *(uint4*)(xwin + swz128(r, c)) = v;
     }
-    __syncthreads();
 
     f32x4 acc[4][2];
 #pragma unroll
@@ -48,37 +59,25 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_kernel(const bf16* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int r16 = lane & 15, cq = lane >> 4;
-    const bf16* wg = W + (size_t)g * KW * 4096 + (size_t)r16 * 64 + cq * 8;   // + kw*4096 + ni*1024 + ks*32
-
-    bf16x8 wf[2][4], wn[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) wf[ks][ni] = *(const bf16x8*)(wg + ni * 1024 + ks * 32);
 
     for (int kw = 0; kw < KW; ++kw) {
-        if (kw + 1 < KW) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) wn[ks][ni] = *(const bf16x8*)(wg + (size_t)(kw + 1) * 4096 + ni * 1024 + ks * 32);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // tap kw landed (and the window, first time); everyone left tap kw-1
+        if (kw + 1 < KW) stage_w(kw + 1, (kw + 1) & 1);
+        const char* wt = wbuf + (kw & 1) * 8192;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[2];
+            bf16x8 wf[4], xf[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                xf[mi] = *(const bf16x8*)(smem + swz128(wave * 32 + mi * 16 + r16 + kw, ks * 4 + cq));
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const bf16x8*)(wt + swz128(ni * 16 + r16, ks * 4 + cq));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const bf16x8*)(xwin + swz128(wave * 32 + mi * 16 + r16 + kw, ks * 4 + cq));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) wf[ks][ni] = wn[ks][ni];
     }
 
     // D[co_local = cq*4 + j][token_local = r16]
@@ -165,12 +164,12 @@ int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err) {
     if (a->dtype == VV_BF16) {
         if ((a->ld_in * 2) % 16 || (uintptr_t)a->in % 16 || (uintptr_t)a->W % 16) { *err = "posconv: alignment"; return -22; }
         dim3 grid((a->seq_n + PC_TOK - 1) / PC_TOK, a->groups, a->n_seq);
-        const size_t lds = (size_t)(PC_TOK + a->KW - 1) * 128;
+        const size_t lds = (size_t)(PC_TOK + a->KW - 1) * 128 + 2 * 8192;
         if (a->out_dtype == VV_BF16)
-            posconv_bf16_kernel<bf16><<<grid, 256, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (bf16*)a->out,
+            posconv_bf16_kernel<bf16><<<grid, 512, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (bf16*)a->out,
                                                               a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
         else
-            posconv_bf16_kernel<float><<<grid, 256, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (float*)a->out,
+            posconv_bf16_kernel<float><<<grid, 512, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (float*)a->out,
                                                                a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
     } else {
         if (a->out_dtype != VV_F32) { *err = "posconv: f32 path writes f32"; return -22; }
