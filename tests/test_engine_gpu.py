@@ -63,3 +63,38 @@ def test_engine_session_io_contract_and_errors(tmp_path):
         e.config.max_chunk_duration = 1.0
         e.synthesize("một câu rất dài " * 30)
     e.cleanup()
+
+
+def test_streaming_equals_buffered_on_device(tmp_path):
+    """N4: streamed blocks concatenate to the buffered PCM (same seed, one chunk per GPU wave vs all chunks in one batch:
+    ragged batching must not change a sequence's result beyond the fp32 summation-order tolerance)."""
+    a = _engine(tmp_path)
+    whole, _ = a.synthesize(LONG)
+    a.cleanup()
+    b = _engine(tmp_path)
+    blocks = list(b.synthesize_stream(LONG, chunks_per_step=1))
+    b.cleanup()
+    got = np.concatenate(blocks)
+    assert len(blocks) > 1 and got.shape == whole.shape
+    assert int(np.abs(got.astype(np.int32) - whole.astype(np.int32)).max()) <= 2
+
+
+def test_batching_frontend_batch_composition_invariance(tmp_path):
+    """N2: a request's audio does not depend on what shared its GPU batch (per-request noise streams, per-item
+    reference clips and lengths on the device); different voices ride in one batch."""
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    e = _engine(tmp_path)
+    fe = BatchingFrontend(e, max_wait_ms=300.0, max_requests=8)
+    try:
+        alone = fe.submit("Xin chào các bạn, hôm nay thế nào?", speed=1.0, serial=7).result(timeout=300)[0]
+        n0 = fe.batches_run
+        futs = [fe.submit("Tạm biệt và hẹn gặp lại.", speed=1.3, serial=8, gender="male"),
+                fe.submit("Xin chào các bạn, hôm nay thế nào?", speed=1.0, serial=7),
+                fe.submit(LONG, speed=0.8, serial=9)]
+        outs = [f.result(timeout=300)[0] for f in futs]
+        assert fe.batches_run == n0 + 1
+        assert outs[1].shape == alone.shape and int(np.abs(outs[1].astype(np.int32) - alone.astype(np.int32)).max()) <= 2
+        assert all(o.dtype == np.int16 and o.size > 0 for o in outs)
+    finally:
+        fe.close()
+        e.cleanup()

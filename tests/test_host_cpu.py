@@ -264,3 +264,35 @@ def test_synthesis_errors_are_wrapped(cpu_engine):
             cpu_engine.synthesize("một câu rất dài " * 40)
         finally:
             cpu_engine.config.max_chunk_duration = old
+
+
+# ------------------------------------------------------------------ next rows N4 (streaming) and N2 (request batching), CPU plumbing
+def test_streaming_equals_buffered(cpu_engine):
+    """N4: the concatenation of the streamed blocks is the buffered result, sample for sample (fresh equal noise streams)."""
+    import torch
+    text = "Hôm nay trời đẹp quá, chúng ta cùng nhau đi dạo quanh hồ nhé. " * 3
+    for sess in cpu_engine.model_session_manager.sessions.values():
+        sess.gen = torch.Generator().manual_seed(123)
+    whole, _ = cpu_engine.synthesize(text)
+    for sess in cpu_engine.model_session_manager.sessions.values():
+        sess.gen = torch.Generator().manual_seed(123)
+    blocks = list(cpu_engine.synthesize_stream(text, chunks_per_step=1))
+    assert len(blocks) == len(cpu_engine._last_plan) > 1
+    assert np.array_equal(np.concatenate(blocks), whole)
+
+
+def test_batching_frontend_plumbing(cpu_engine):
+    """N2: concurrent requests with their own speed are coalesced; results come back per request; errors keep their types."""
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    fe = BatchingFrontend(cpu_engine, max_wait_ms=200.0, max_requests=8)
+    try:
+        futs = [fe.submit("Xin chào các bạn.", speed=0.9), fe.submit("Tạm biệt.", speed=1.5, gender="male", group="news", area="southern", emotion="serious"),
+                fe.submit("x", gender="robot")]
+        a, b = futs[0].result(timeout=300), futs[1].result(timeout=300)
+        assert a[0].dtype == np.int16 and b[0].dtype == np.int16 and a[0].size > 0 and b[0].size > 0
+        with pytest.raises(ValueError, match="Invalid gender"):
+            futs[2].result(timeout=60)
+        assert fe.batches_run == 1 and fe.requests_done == 2          # one coalesced batch served both good requests
+        assert cpu_engine.config.speed == 0.9                         # per-request speed never touches the shared config
+    finally:
+        fe.close()

@@ -127,47 +127,55 @@ class TTSEngine:
         return waves
 
     # ------------------------------------------------------------------ device-resident batched path
-    def _synthesize_device(self, inputs_list) -> List[np.ndarray]:
+    def _synthesize_device(self, inputs_list, noise_blocks=None) -> List[np.ndarray]:
+        """inputs_list items are (audio (1,1,S_i), text_ids (1,T_i), max_duration (1,), time_step); the reference
+        clips may differ per item (cross-request batches).  One ragged GPU batch per ``max_batch_chunks`` items.
+        noise_blocks: optional pre-drawn (N_i, n_mel) fp32 tensors, one per item (the batching front end draws them from
+        per-request generators); default = the manager's seeded stream, in item order, like the session path."""
         import torch
         m = self.model_session_manager
         eng, spec = m.engine, m.spec
         dev = eng.device
         eng.set_nfe(self.config.nfe_step)
+        hop = self.config.hop_length
         waves: List[np.ndarray] = []
         step = max(1, int(self.config.max_batch_chunks))
         for lo in range(0, len(inputs_list), step):
             group = inputs_list[lo: lo + step]
             B = len(group)
-            S = group[0][0].shape[-1]
-            T = max(g[1].shape[1] for g in group)
+            lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)
+            lens_t = np.array([g[1].shape[1] for g in group], dtype=np.int32)
+            S, T = int(lens_a.max()), int(lens_t.max())
+            audio_np = np.zeros((B, S), dtype=np.int16)
             ids = np.zeros((B, T), dtype=np.int32)
             for i, g in enumerate(group):
-                ids[i, : g[1].shape[1]] = g[1][0]
+                audio_np[i, : lens_a[i]] = g[0].reshape(-1)
+                ids[i, : lens_t[i]] = g[1][0]
             seq = np.array([int(g[2][0]) for g in group], dtype=np.int32)
+            ref_frames = lens_a // hop + 1
             N = int(seq.max())
-            ref_frames = S // self.config.hop_length + 1
-            audio = torch.from_numpy(np.ascontiguousarray(np.repeat(group[0][0].reshape(1, -1), B, axis=0))).to(dev)
+            t_gen = int((seq - ref_frames).max())
+            if self.config.use_hip_graph:
+                # fixed frame buckets (multiples of 128) so that one captured vocoder graph serves every chunk group
+                N = (N + 127) // 128 * 128
+                t_gen = N - int(ref_frames.min())
             # the same seeded stream the session path draws from, one (N_i, n_mel) block per chunk in order
             noise = torch.zeros((B, N, spec.n_mel), dtype=torch.float32)
             for i in range(B):
-                noise[i, : seq[i]] = torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32)
+                noise[i, : seq[i]] = (noise_blocks[lo + i] if noise_blocks is not None else
+                                      torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32))
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-            t_gen = int(seq.max()) - ref_frames
+            audio = torch.from_numpy(audio_np).to(dev)
             if self.config.use_hip_graph:
-                # fixed frame buckets (multiples of 128) so that one captured vocoder graph serves every chunk group
-                Nb = (N + 127) // 128 * 128
-                noise_b = torch.zeros((B, Nb, spec.n_mel), dtype=torch.float32)
-                noise_b[:, :N] = noise
-                pre = eng.preprocess(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]), t32(seq), Nb)
-                x = noise_b.to(dev)
+                pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N)
+                x = noise.to(dev)
                 eng.transformer_steps(x, pre, 0, eng.n_steps)
-                key = (B, Nb, Nb - ref_frames)
+                key = (B, N, t_gen)
                 if key not in self._decode_graphs:
                     self._decode_graphs[key] = eng.capture_decode(*key)
                 pcm, pcm_len = self._decode_graphs[key](x, pre["ref_signal_len"], pre["seq_len"])
             else:
-                _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(np.full(B, S)), t32(ids), t32([g[1].shape[1] for g in group]),
-                                                             t32(seq), N, noise.to(dev), t_gen)
+                _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen)
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
             for i in range(B):
                 waves.append(pcm[i, : pcm_len[i]].reshape(1, 1, -1))
@@ -196,6 +204,42 @@ class TTSEngine:
                 self.audio_processor.save_audio(final_wave, output_path, self.config.sample_rate)
                 logger.info("Audio saved to: %s", output_path)
             return final_wave, generation_time
+        except Exception as e:
+            raise RuntimeError(f"Speech synthesis failed: {str(e)}")
+
+    def synthesize_stream(self, text: str, gender: Optional[str] = None, group: Optional[str] = None, area: Optional[str] = None,
+                          emotion: Optional[str] = None, sample_iteration: Optional[int] = None,
+                          reference_audio: Optional[str] = None, reference_text: Optional[str] = None, chunks_per_step: int = 1):
+        """Generator of int16 PCM blocks: audio is emitted as soon as a group of ``chunks_per_step``
+        chunks is synthesised instead of after the whole text (the reference buffers everything, api/app.py:59-65).
+        Overlap-save: the improved cross-fade only rewrites the last ``cross_fade_duration`` of what has been joined
+        so far (audio_processor.py:122-192), so everything before that tail is final and can be yielded; the
+        concatenation of all yielded blocks equals ``synthesize(text)`` sample for sample."""
+        speed = self.config.speed
+        ref_audio, ref_text = self.model_session_manager.select_sample(gender, group, area, emotion, sample_iteration,
+                                                                       reference_audio, reference_text)
+        try:
+            with self._lock:
+                inputs_list = self._prepare_inputs(ref_audio, ref_text, text, speed=speed)
+            self._last_plan = [int(i[2][0]) for i in inputs_list]
+            cf = int(self.config.cross_fade_duration * self.config.sample_rate)
+            joined, emitted = None, 0
+            step = max(1, int(chunks_per_step))
+            for lo in range(0, len(inputs_list), step):
+                with self._lock:
+                    if self.model_session_manager.engine is not None:
+                        waves = self._synthesize_device(inputs_list[lo: lo + step])
+                    else:
+                        waves = self._synthesize_sessions(inputs_list[lo: lo + step])
+                for w in waves:
+                    parts = [w] if joined is None else [joined, w]
+                    joined = self.audio_processor.concatenate_with_crossfade_improved(parts, self.config.cross_fade_duration,
+                                                                                      self.config.sample_rate)
+                last = lo + step >= len(inputs_list)
+                upto = len(joined) if last else max(emitted, len(joined) - cf)
+                if upto > emitted:
+                    yield np.ascontiguousarray(joined[emitted:upto])
+                    emitted = upto
         except Exception as e:
             raise RuntimeError(f"Speech synthesis failed: {str(e)}")
 
