@@ -182,13 +182,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the synthesis hot path has no CPU fallback")
+    backend = os.environ.get("VV_BENCH_DIST_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the N>1 path (ranks share cuda:0)
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # backend "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     spec = {"full": ModelSpec.full, "small": ModelSpec.small, "tiny": ModelSpec.tiny}[a.spec]()
     adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
