@@ -181,6 +181,18 @@ int vv_groupnorm(vv_ctx* ctx, const float* x, float* y, const float* gamma, cons
 int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
 int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
 
+/* ---- reference-clip ingest on the device.  Together they replace the arithmetic of
+ * AudioProcessor.load_audio after decoding (reference core/audio_processor.py:16-44: set_frame_rate, then
+ * normalize_to_int16 = remove DC, peak -> 29491, truncate). */
+/* polyphase FIR resampler: y[n] = sum_i x[i] * taps[(n + skip) * down - i * up], f64 accumulate, f32 out.
+ * taps = host-designed low-pass already scaled by `up` (f64, device). */
+int vv_resample_poly(vv_ctx* ctx, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip,
+                     float* y, int n_out, void* stream);
+/* n_clips mono f32 clips stored back to back, clip i = [offsets[i], offsets[i+1]); out has the same offsets.
+ * stats = 2 * n_clips doubles of device scratch. */
+int vv_normalize_clips(vv_ctx* ctx, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats,
+                       int16_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ class TTSEngine:
         self.text_processor = TextProcessor(self.model_session_manager.vocab_path)
         self.audio_processor = AudioProcessor()
         self.sample_cache = {}
+        self.voice_bank = None                    # N3: device-resident reference clips (HIP engine only)
+        if self.model_session_manager.engine is not None:
+            from ..voice_bank import VoiceBank
+            self.voice_bank = VoiceBank(self.model_session_manager.engine, self.config.sample_rate)
         self._lock = threading.Lock()
         self._decode_graphs = {}
         self._last_plan = []
@@ -65,7 +69,10 @@ class TTSEngine:
                         speed: Optional[float] = None) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]]:
         cfg = self.config
         speed = cfg.speed if speed is None else speed
-        audio = self.audio_processor.load_audio(reference_audio_path_or_bytes, cfg.sample_rate).reshape(1, 1, -1)
+        if getattr(self, "voice_bank", None) is not None:   # decoded / resampled / normalised once on the GPU, then cached in HBM
+            audio = self.voice_bank.get(reference_audio_path_or_bytes).pcm_host.reshape(1, 1, -1)
+        else:
+            audio = self.audio_processor.load_audio(reference_audio_path_or_bytes, cfg.sample_rate).reshape(1, 1, -1)
         reference_text = self.text_processor.clean_text(reference_text)
         target_text = self.text_processor.clean_text(target_text)
 
@@ -146,11 +153,19 @@ class TTSEngine:
             lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)
             lens_t = np.array([g[1].shape[1] for g in group], dtype=np.int32)
             S, T = int(lens_a.max()), int(lens_t.max())
-            audio_np = np.zeros((B, S), dtype=np.int16)
             ids = np.zeros((B, T), dtype=np.int32)
             for i, g in enumerate(group):
-                audio_np[i, : lens_a[i]] = g[0].reshape(-1)
                 ids[i, : lens_t[i]] = g[1][0]
+            banked = [self.voice_bank.entry_for_host(g[0]) if self.voice_bank is not None else None for g in group]
+            if all(e is not None for e in banked):               # clips already live in HBM: assemble the batch device-side
+                audio = torch.zeros((B, S), dtype=torch.int16, device=dev)
+                for i, e in enumerate(banked):
+                    audio[i, : lens_a[i]] = e.pcm_dev
+            else:
+                audio_np = np.zeros((B, S), dtype=np.int16)
+                for i, g in enumerate(group):
+                    audio_np[i, : lens_a[i]] = g[0].reshape(-1)
+                audio = torch.from_numpy(audio_np).to(dev)
             seq = np.array([int(g[2][0]) for g in group], dtype=np.int32)
             ref_frames = lens_a // hop + 1
             N = int(seq.max())
@@ -165,7 +180,6 @@ class TTSEngine:
                 noise[i, : seq[i]] = (noise_blocks[lo + i] if noise_blocks is not None else
                                       torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32))
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-            audio = torch.from_numpy(audio_np).to(dev)
             if self.config.use_hip_graph:
                 pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N)
                 x = noise.to(dev)

@@ -602,6 +602,12 @@ int vv_groupnorm(vv_ctx* c, const float* x, float* y, const float* gamma, const 
 int vv_rope_compact(vv_ctx* c, const float* cos_t, const float* sin_t, float* out, int n, void* st) {
     SINGLE(c, vvk_rope_compact(cos_t, sin_t, out, n, (hipStream_t)st, &m__));
 }
+int vv_resample_poly(vv_ctx* c, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip, float* y, int n_out, void* st) {
+    SINGLE(c, vvk_resample_poly(x, n_in, taps, n_taps, up, down, skip, y, n_out, (hipStream_t)st, &m__));
+}
+int vv_normalize_clips(vv_ctx* c, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats, int16_t* out, void* st) {
+    SINGLE(c, vvk_normalize_clips(x, (const long long*)offsets, n_clips, (long long)max_len, stats, out, (hipStream_t)st, &m__));
+}
 int vv_cfg_euler(vv_ctx* c, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* st) {
     SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, (hipStream_t)st, &m__));
 }

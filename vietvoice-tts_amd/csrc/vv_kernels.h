@@ -36,6 +36,10 @@ int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int
                    const char** err);
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err);
 int vvk_silu(float* x, size_t n, hipStream_t st, const char** err);
+int vvk_resample_poly(const float* x, int n_in, const double* h, int n_taps, int up, int down, int skip, float* y, int n_out,
+                      hipStream_t st, const char** err);
+int vvk_normalize_clips(const float* x, const long long* off, int n_clips, long long max_len, double* stats, int16_t* out,
+                        hipStream_t st, const char** err);
 int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err);
 int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err);
 int vvk_groupnorm(const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act,

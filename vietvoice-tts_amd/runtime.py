@@ -108,6 +108,8 @@ EXPORTS = {
                                C.c_int, C.c_void_p]),
     "vv_rope_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "vv_resample_poly": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_normalize_clips": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -297,6 +299,27 @@ class HipSynth:
         """Capture the decode stage (frame slice -> vocoder -> int16) for a fixed shape into a hipGraph.
         Long-form synthesis replays it per chunk group: ~80 launches become one graph launch."""
         return GraphedDecode(self, B, N, t_gen_max)
+
+    # ------------------------------------------------------------------ reference-clip ingest (N3)
+    def resample_poly(self, x: torch.Tensor, taps: torch.Tensor, up: int, down: int, skip: int, n_out: int) -> torch.Tensor:
+        """x f32 [n_in] and taps f64 [n_taps] on the device -> f32 [n_out]."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and taps.is_cuda and taps.dtype == torch.float64
+        y = torch.empty((n_out,), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_resample_poly(self.ctx, x.data_ptr(), x.numel(), taps.data_ptr(), taps.numel(), up, down, skip,
+                                                  y.data_ptr(), n_out, self._stream()))
+        return y
+
+    def normalize_clips(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+        """x f32 [total] = clips back to back, offsets int64 [n+1] (device) -> int16 [total] (DC removed, peak 29491)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int64
+        n = offsets.numel() - 1
+        out = torch.empty((x.numel(),), dtype=torch.int16, device=self.device)
+        stats = torch.empty((2 * n,), dtype=torch.float64, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, x.numel(), stats.data_ptr(),
+                                                    out.data_ptr(), self._stream()))
+        return out
 
     # ------------------------------------------------------------------ profiling
     def prof_enable(self, on: bool):

@@ -1,0 +1,130 @@
+"""Device-resident voice bank: reference clips are decoded once, resampled + DC/peak-normalised
+ON THE GPU, and kept in HBM keyed by content, so a request for a known voice costs a dictionary lookup.
+
+The reference re-opens the model tar, re-decodes and re-normalises the clip on every call
+(core/model.py:204-211, core/audio_processor.py:16-44) and carries an unused ``sample_cache``
+(core/tts_engine.py:30).  Here:
+
+  host   : RIFF/WAVE byte parsing (no arithmetic), FIR design for the resampler (a few hundred taps)
+  device : polyphase resampling (vv_resample_poly), mean / peak / scale / int16 truncation (vv_normalize_clips),
+           clips of one ``ingest_many`` call batched on grid.y
+
+An entry keeps the int16 clip on the device (what vv_preprocess reads) plus one host copy (what the reference-style
+session path and the duration model read).  LRU eviction by a byte budget; 239 built-in voices of ~8 s are ~90 MB.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+from collections import OrderedDict
+from math import gcd
+from typing import Dict, List, Tuple, Union
+
+import numpy as np
+
+from .core.audio_processor import AudioProcessor
+
+
+def resample_design(src: int, dst: int) -> Tuple[np.ndarray, int, int, int]:
+    """(taps f64 with the leading zero pad, up, down, skip): the filter the host mirror's polyphase resampler uses
+    (Kaiser beta 5, half length 10 * max(up, down), gain = up), cut so that y[n] = sum_i x[i] * taps[(n+skip)*down - i*up]."""
+    from scipy.signal import firwin
+    g = gcd(src, dst)
+    up, down = dst // g, src // g
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = down - half_len % down
+    skip = (half_len + n_pre_pad) // down
+    return np.concatenate([np.zeros(n_pre_pad), h]).astype(np.float64), up, down, skip
+
+
+class VoiceEntry:
+    __slots__ = ("key", "pcm_dev", "pcm_host", "n_samples", "nbytes")
+
+    def __init__(self, key, pcm_dev, pcm_host):
+        self.key, self.pcm_dev, self.pcm_host = key, pcm_dev, pcm_host
+        self.n_samples = int(pcm_host.shape[0])
+        self.nbytes = self.n_samples * 2
+
+
+class VoiceBank:
+    def __init__(self, synth, sample_rate: int, max_bytes: int = 1 << 30):
+        self.synth, self.sample_rate, self.max_bytes = synth, int(sample_rate), int(max_bytes)
+        self._entries: "OrderedDict[str, VoiceEntry]" = OrderedDict()
+        self._by_host: Dict[int, VoiceEntry] = {}
+        self._taps = {}
+        self.bytes = 0
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def key_of(path_or_bytes: Union[str, bytes]) -> str:
+        if isinstance(path_or_bytes, str):
+            st = os.stat(path_or_bytes)           # FileNotFoundError propagates like the reference's check (:19-20)
+            return f"file:{os.path.abspath(path_or_bytes)}:{st.st_mtime_ns}:{st.st_size}"
+        return "sha1:" + hashlib.sha1(bytes(path_or_bytes)).hexdigest()
+
+    def get(self, path_or_bytes: Union[str, bytes]) -> VoiceEntry:
+        return self.ingest_many([path_or_bytes])[0]
+
+    def entry_for_host(self, pcm_host: np.ndarray):
+        """The entry whose host copy is this very array (how _synthesize_device finds the device clip of an input tuple)."""
+        base = pcm_host.base if pcm_host.base is not None else pcm_host
+        return self._by_host.get(id(base))
+
+    def ingest_many(self, items: List[Union[str, bytes]]) -> List[VoiceEntry]:
+        import torch
+        keys = []
+        for it in items:
+            if isinstance(it, str) and not os.path.exists(it):
+                raise FileNotFoundError(f"Audio file not found: {it}")
+            keys.append(self.key_of(it))
+        todo: Dict[str, Union[str, bytes]] = {}
+        for k, it in zip(keys, items):
+            if k in self._entries:
+                self.hits += 1
+                self._entries.move_to_end(k)
+            elif k not in todo:
+                self.misses += 1
+                todo[k] = it
+            else:
+                self.hits += 1                    # repeated inside this call: ingested once
+        if todo:
+            dev = self.synth.device
+            clips = []
+            for k, it in todo.items():
+                x, rate = AudioProcessor._read(it)                     # host: container parsing only
+                xd = torch.from_numpy(x).to(dev)
+                if rate != self.sample_rate and x.size:
+                    if rate not in self._taps:
+                        taps, up, down, skip = resample_design(rate, self.sample_rate)
+                        self._taps[rate] = (torch.from_numpy(taps).to(dev), up, down, skip)
+                    taps, up, down, skip = self._taps[rate]
+                    n_out = -(-(x.size * up) // down)
+                    xd = self.synth.resample_poly(xd, taps, up, down, skip, n_out)
+                clips.append(xd)
+            lens = [int(c.numel()) for c in clips]
+            if any(n == 0 for n in lens):
+                raise ValueError("empty audio clip")
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            pcm = self.synth.normalize_clips(torch.cat(clips) if len(clips) > 1 else clips[0], torch.from_numpy(off).to(dev))
+            host = pcm.cpu().numpy()
+            for j, k in enumerate(todo):
+                e = VoiceEntry(k, pcm[off[j]: off[j + 1]].clone(), host[off[j]: off[j + 1]].copy())
+                self._entries[k] = e
+                self._by_host[id(e.pcm_host)] = e
+                self.bytes += e.nbytes
+            while self.bytes > self.max_bytes and len(self._entries) > len(set(keys)):
+                k0 = next(iter(self._entries))
+                if k0 in keys:
+                    self._entries.move_to_end(k0)
+                    continue
+                old = self._entries.pop(k0)
+                self._by_host.pop(id(old.pcm_host), None)
+                self.bytes -= old.nbytes
+        return [self._entries[k] for k in keys]
+
+    def clear(self):
+        self._entries.clear()
+        self._by_host.clear()
+        self.bytes = 0
