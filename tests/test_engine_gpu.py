@@ -136,3 +136,29 @@ def test_voice_bank_cache_and_parity(tmp_path):
     w_host = e._synthesize_device(host_ins, noise_blocks=blk)[0]
     e.cleanup()
     assert w_bank.shape == w_host.shape and int(np.abs(w_bank.astype(np.int32) - w_host.astype(np.int32)).max()) <= 2
+
+
+def test_engine_from_reference_layout_onnx_archive(tmp_path):
+    """N1: an archive in the reference's layout (preprocess/transformer/decode .onnx, no model_spec.json) goes through the
+    protobuf reader -> name recovery -> shape-inferred spec -> device weight pack, and the HIP engine produces the very
+    PCM the synthetic pack with the same weights produces.  (The real archive's naming is unpinned: see onnx_import.py.)"""
+    import tarfile
+    from vietvoice_tts_amd import onnx_import as oi
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    a = _engine(tmp_path)
+    wa, _ = a.synthesize("Xin chào các bạn.")
+    a.cleanup()
+    d2 = tmp_path / "onnx"
+    d2.mkdir()
+    members = {}
+    with tarfile.open(tmp_path / "model-bin.pt") as tar:
+        for n in tar.getnames():
+            if n != "model_spec.json":
+                members[n] = tar.extractfile(n).read()
+    spec = ModelSpec.tiny()
+    oi.write_onnx_archive(str(d2 / "model-bin.pt"), spec, make_synthetic_weights(spec, 9527), members)
+    b = _engine(d2)
+    assert b.model_session_manager.spec == spec
+    wb, _ = b.synthesize("Xin chào các bạn.")
+    b.cleanup()
+    assert np.array_equal(wa, wb)

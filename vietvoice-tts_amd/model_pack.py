@@ -82,10 +82,9 @@ def read_pack_model(tar: tarfile.TarFile) -> Tuple[ModelSpec, Dict[str, torch.Te
     """-> (spec, fp32 weights in torch-native layouts)."""
     names = tar.getnames()
     if "model_spec.json" not in names:
-        onnx = [n for n in names if n.endswith(".onnx")]
-        if onnx:
-            raise RuntimeError("this archive carries the reference's ONNX graphs (%s); importing ONNX initializers is not "
-                               "implemented in this build (SURVEY.md 8(f) N1)" % ", ".join(onnx))
+        if any(n.endswith(".onnx") for n in names):        # the reference's own layout (core/model.py:73-110): read the initializers
+            from .onnx_import import import_archive
+            return import_archive(tar)
         raise FileNotFoundError("Model file 'model_spec.json' not found in model archive")
     doc = json.load(tar.extractfile("model_spec.json"))
     spec = ModelSpec.from_json(json.dumps(doc["spec"]))

@@ -1,0 +1,620 @@
+"""ONNX initializer importer: read the weights out of the reference's model archive.
+
+The reference's ``model-bin.pt`` is a tar with ``preprocess.onnx`` / ``transformer.onnx`` / ``decode.onnx`` next to
+``vocab.txt`` and the voice bank (core/model.py:73-110).  Neither ``onnx`` nor ``onnxruntime`` exists offline, so
+this module reads the protobuf wire format directly -- ModelProto -> GraphProto -> {NodeProto, TensorProto,
+ValueInfoProto}, field numbers from the public onnx.proto3 -- and nothing in a file is ever executed.
+
+  parse_model(bytes)          -> OnnxModel (nodes, initializers as numpy arrays, graph inputs / outputs)
+  recover_names(model)        -> {torch-style parameter name: array}; the torch exporter renames Linear weights to
+                                 ``onnx::MatMul_<n>`` (stored transposed) but keeps the bias name on the following Add,
+                                 so the weight name is recovered from its bias
+  infer_spec(pre, tr, dec)    -> ModelSpec constants read off tensor shapes, node counts and node attributes
+  import_archive(tar)         -> (spec, weights in this build's names / layouts) through NAME_RULES
+  export_archive_members(...) -> the inverse (this build's weights written as ONNX initializers with exporter-style
+                                 naming), used to make fixtures and to hand weights to ONNX tooling
+
+PARITY UNPINNED: the real archive cannot be fetched here, so NAME_RULES follows the public F5-TTS / HiFi-GAN
+module naming and is exercised only on graphs written by ``export_archive_members``.  A graph that does not match
+(for instance a vocoder without ConvTranspose nodes) raises UnsupportedGraph naming what was found.
+"""
+from __future__ import annotations
+
+import io
+import re
+import struct
+import tarfile
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+
+class UnsupportedGraph(RuntimeError):
+    pass
+
+
+# ------------------------------------------------------------------ protobuf wire format
+def _varint(buf: memoryview, pos: int) -> Tuple[int, int]:
+    res = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        res |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return res, pos
+        shift += 7
+        if shift > 70:
+            raise ValueError("malformed varint")
+
+
+def _fields(buf: memoryview) -> Iterable[Tuple[int, int, object]]:
+    """Yield (field number, wire type, value); value = int for varint / fixed, memoryview for length-delimited."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        fno, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt in (1, 5) and pos + (8 if wt == 1 else 4) > n:
+            raise ValueError("truncated fixed-width field")
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]
+            pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            if pos + ln > n:
+                raise ValueError("truncated length-delimited field")
+            v = buf[pos: pos + ln]
+            pos += ln
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]
+            pos += 4
+        else:
+            raise ValueError(f"unsupported protobuf wire type {wt}")
+        yield fno, wt, v
+
+
+def _sint(v: int) -> int:
+    """protobuf int64 carried as an unsigned 64-bit varint -> Python int."""
+    return v - (1 << 64) if v >= 1 << 63 else v
+
+
+def _packed_varints(v, wt) -> List[int]:
+    if wt == 0:
+        return [_sint(v)]
+    out, pos = [], 0
+    while pos < len(v):
+        x, pos = _varint(v, pos)
+        out.append(_sint(x))
+    return out
+
+
+_DTYPES = {1: np.float32, 2: np.uint8, 3: np.int8, 4: np.uint16, 5: np.int16, 6: np.int32, 7: np.int64, 9: np.bool_,
+           10: np.float16, 11: np.float64, 12: np.uint32, 13: np.uint64}
+_BF16 = 16
+
+
+def _tensor(buf: memoryview) -> Tuple[str, np.ndarray]:
+    dims: List[int] = []
+    dtype = 0
+    name = ""
+    raw = None
+    f32: List[np.ndarray] = []
+    i32: List[int] = []
+    i64: List[int] = []
+    f64: List[np.ndarray] = []
+    for fno, wt, v in _fields(buf):
+        if fno == 1:
+            dims += _packed_varints(v, wt)
+        elif fno == 2:
+            dtype = v
+        elif fno == 4:
+            f32.append(np.frombuffer(v, dtype="<f4") if wt == 2 else np.array([struct.unpack("<f", struct.pack("<I", v))[0]], np.float32))
+        elif fno == 5:
+            i32 += _packed_varints(v, wt)
+        elif fno == 7:
+            i64 += _packed_varints(v, wt)
+        elif fno == 8:
+            name = bytes(v).decode("utf-8")
+        elif fno == 9:
+            raw = v
+        elif fno == 10:
+            f64.append(np.frombuffer(v, dtype="<f8") if wt == 2 else np.array([struct.unpack("<d", struct.pack("<Q", v))[0]]))
+        elif fno == 14 and v == 1:
+            raise UnsupportedGraph(f"initializer {name!r} keeps its data in an external file; only in-file tensors are read")
+    shape = tuple(dims)
+    count = int(np.prod(shape)) if shape else 1
+    if dtype == _BF16:                                   # bfloat16: upper half of an f32
+        bits = np.frombuffer(raw, dtype="<u2") if raw is not None else np.array(i32, dtype=np.uint16)
+        arr = (bits.astype(np.uint32) << 16).view(np.float32)
+    elif dtype in _DTYPES:
+        dt = np.dtype(_DTYPES[dtype])
+        if raw is not None:
+            arr = np.frombuffer(raw, dtype=dt.newbyteorder("<"))
+        elif f32:
+            arr = np.concatenate(f32).astype(dt)
+        elif f64:
+            arr = np.concatenate(f64).astype(dt)
+        elif i64:
+            arr = np.array(i64, dtype=dt)
+        elif dtype == 10:
+            arr = np.array(i32, dtype=np.uint16).view(np.float16)      # fp16 bit patterns travel in int32_data
+        else:
+            arr = np.array(i32, dtype=dt)
+    else:
+        raise UnsupportedGraph(f"initializer {name!r}: tensor data type {dtype} is not handled")
+    if arr.size != count:
+        raise ValueError(f"initializer {name!r}: {arr.size} elements for shape {shape}")
+    return name, arr.reshape(shape)
+
+
+@dataclass
+class OnnxNode:
+    op_type: str
+    name: str
+    inputs: List[str]
+    outputs: List[str]
+    attrs: Dict[str, object] = field(default_factory=dict)
+
+
+@dataclass
+class OnnxValue:
+    name: str
+    elem_type: int
+    shape: Tuple[object, ...]
+
+
+@dataclass
+class OnnxModel:
+    ir_version: int
+    opset: Dict[str, int]
+    producer: str
+    graph_name: str
+    nodes: List[OnnxNode]
+    initializers: Dict[str, np.ndarray]
+    inputs: List[OnnxValue]            # graph inputs that are not initializers
+    outputs: List[OnnxValue]
+
+
+def _attribute(buf: memoryview) -> Tuple[str, object]:
+    name, val = "", None
+    floats: List[float] = []
+    ints: List[int] = []
+    for fno, wt, v in _fields(buf):
+        if fno == 1:
+            name = bytes(v).decode()
+        elif fno == 2:
+            val = struct.unpack("<f", struct.pack("<I", v))[0]
+        elif fno == 3:
+            val = _sint(v)
+        elif fno == 4:
+            val = bytes(v)
+        elif fno == 5:
+            val = _tensor(v)[1]
+        elif fno == 7:
+            floats += list(np.frombuffer(v, "<f4")) if wt == 2 else [struct.unpack("<f", struct.pack("<I", v))[0]]
+        elif fno == 8:
+            ints += _packed_varints(v, wt)
+    if val is None:
+        val = ints if ints else floats
+    return name, val
+
+
+def _node(buf: memoryview) -> OnnxNode:
+    n = OnnxNode("", "", [], [])
+    for fno, _wt, v in _fields(buf):
+        if fno == 1:
+            n.inputs.append(bytes(v).decode())
+        elif fno == 2:
+            n.outputs.append(bytes(v).decode())
+        elif fno == 3:
+            n.name = bytes(v).decode()
+        elif fno == 4:
+            n.op_type = bytes(v).decode()
+        elif fno == 5:
+            k, a = _attribute(v)
+            n.attrs[k] = a
+    return n
+
+
+def _value_info(buf: memoryview) -> OnnxValue:
+    name, elem, shape = "", 0, []
+    for fno, _wt, v in _fields(buf):
+        if fno == 1:
+            name = bytes(v).decode()
+        elif fno == 2:                                           # TypeProto
+            for f2, _w2, v2 in _fields(v):
+                if f2 != 1:                                      # tensor_type
+                    continue
+                for f3, _w3, v3 in _fields(v2):
+                    if f3 == 1:
+                        elem = v3
+                    elif f3 == 2:                                # TensorShapeProto
+                        for f4, _w4, v4 in _fields(v3):
+                            if f4 != 1:
+                                continue
+                            dim: object = None
+                            for f5, _w5, v5 in _fields(v4):
+                                if f5 == 1:
+                                    dim = _sint(v5)
+                                elif f5 == 2:
+                                    dim = bytes(v5).decode()
+                            shape.append(dim)
+    return OnnxValue(name, elem, tuple(shape))
+
+
+def parse_model(data: bytes) -> OnnxModel:
+    buf = memoryview(data)
+    ir, producer, opset, graph = 0, "", {}, None
+    for fno, _wt, v in _fields(buf):
+        if fno == 1:
+            ir = v
+        elif fno == 2:
+            producer = bytes(v).decode()
+        elif fno == 7:
+            graph = v
+        elif fno == 8:
+            dom, ver = "", 0
+            for f2, _w2, v2 in _fields(v):
+                if f2 == 1:
+                    dom = bytes(v2).decode()
+                elif f2 == 2:
+                    ver = v2
+            opset[dom] = ver
+    if graph is None:
+        raise ValueError("not an ONNX ModelProto: no graph")
+    nodes, inits, ins, outs, gname = [], {}, [], [], ""
+    for fno, _wt, v in _fields(graph):
+        if fno == 1:
+            nodes.append(_node(v))
+        elif fno == 2:
+            gname = bytes(v).decode()
+        elif fno == 5:
+            k, a = _tensor(v)
+            inits[k] = a
+        elif fno == 11:
+            ins.append(_value_info(v))
+        elif fno == 12:
+            outs.append(_value_info(v))
+    return OnnxModel(ir, opset, producer, gname, nodes, inits, [i for i in ins if i.name not in inits], outs)
+
+
+# ------------------------------------------------------------------ minimal writer (fixtures / export)
+def _enc_varint(x: int) -> bytes:
+    x &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = x & 0x7F
+        x >>= 7
+        out.append(b | (0x80 if x else 0))
+        if not x:
+            return bytes(out)
+
+
+def _ld(fno: int, payload: bytes) -> bytes:
+    return _enc_varint(fno << 3 | 2) + _enc_varint(len(payload)) + payload
+
+
+def _vi(fno: int, x: int) -> bytes:
+    return _enc_varint(fno << 3) + _enc_varint(x)
+
+
+_ONNX_TYPE = {np.dtype(v): k for k, v in _DTYPES.items()}
+
+
+def encode_tensor(name: str, arr: np.ndarray, how: str = "raw") -> bytes:
+    """how: raw (raw_data), typed (float_data / int64_data / int32_data packed), bf16 (f32 rounded to bf16 raw_data)."""
+    arr = np.asarray(arr)
+    out = b"".join(_vi(1, d) for d in arr.shape)
+    if how == "bf16":
+        u = np.ascontiguousarray(arr, dtype=np.float32).view(np.uint32)
+        bits = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype("<u2")
+        return out + _vi(2, _BF16) + _ld(8, name.encode()) + _ld(9, bits.tobytes())
+    out += _vi(2, _ONNX_TYPE[arr.dtype]) + _ld(8, name.encode())
+    if how == "raw":
+        return out + _ld(9, np.ascontiguousarray(arr).astype(arr.dtype.newbyteorder("<")).tobytes())
+    flat = arr.reshape(-1)
+    if arr.dtype == np.float32:
+        return out + _ld(4, flat.astype("<f4").tobytes())
+    if arr.dtype == np.float64:
+        return out + _ld(10, flat.astype("<f8").tobytes())
+    if arr.dtype == np.int64:
+        return out + _ld(7, b"".join(_enc_varint(int(x)) for x in flat))
+    if arr.dtype == np.float16:
+        return out + _ld(5, b"".join(_enc_varint(int(x)) for x in flat.view(np.uint16)))
+    return out + _ld(5, b"".join(_enc_varint(int(x)) for x in flat))
+
+
+def _enc_attr(name: str, v) -> bytes:
+    out = _ld(1, name.encode())
+    if isinstance(v, float):
+        return out + _enc_varint(2 << 3 | 5) + struct.pack("<f", v) + _vi(20, 1)
+    if isinstance(v, int):
+        return out + _vi(3, v) + _vi(20, 2)
+    if isinstance(v, bytes):
+        return out + _ld(4, v) + _vi(20, 3)
+    if isinstance(v, np.ndarray):
+        return out + _ld(5, encode_tensor("", v)) + _vi(20, 4)
+    if v and isinstance(v[0], float):
+        return out + _ld(7, np.asarray(v, "<f4").tobytes()) + _vi(20, 6)
+    return out + b"".join(_vi(8, int(x)) for x in v) + _vi(20, 7)          # unpacked repeated ints, as protobuf2-era writers emit
+
+
+def encode_node(n: OnnxNode) -> bytes:
+    return (b"".join(_ld(1, s.encode()) for s in n.inputs) + b"".join(_ld(2, s.encode()) for s in n.outputs) + _ld(3, n.name.encode())
+            + _ld(4, n.op_type.encode()) + b"".join(_ld(5, _enc_attr(k, v)) for k, v in n.attrs.items()))
+
+
+def _enc_value(v: OnnxValue) -> bytes:
+    dims = b"".join(_ld(1, _ld(2, d.encode()) if isinstance(d, str) else _vi(1, int(d))) for d in v.shape)
+    return _ld(1, v.name.encode()) + _ld(2, _ld(1, _vi(1, v.elem_type) + _ld(2, dims)))
+
+
+def encode_model(nodes: List[OnnxNode], initializers: List[Tuple[str, np.ndarray, str]], inputs: List[OnnxValue],
+                 outputs: List[OnnxValue], graph_name: str = "main_graph", opset: int = 17, producer: str = "pytorch") -> bytes:
+    g = (b"".join(_ld(1, encode_node(n)) for n in nodes) + _ld(2, graph_name.encode())
+         + b"".join(_ld(5, encode_tensor(k, a, how)) for k, a, how in initializers)
+         + b"".join(_ld(11, _enc_value(v)) for v in inputs) + b"".join(_ld(12, _enc_value(v)) for v in outputs))
+    return _vi(1, 8) + _ld(2, producer.encode()) + _ld(7, g) + _ld(8, _ld(1, b"") + _vi(2, opset))
+
+
+# ------------------------------------------------------------------ exporter-style names
+def recover_names(model: OnnxModel) -> Dict[str, np.ndarray]:
+    """Initializers under torch parameter names.  Named tensors are kept; an anonymous MatMul weight (``onnx::MatMul_7``,
+    stored [in, out]) takes the name of the bias added to its product (``x.bias`` -> ``x.weight``) and is transposed
+    back to torch's [out, in]; Gemm(transB=1) weights keep torch's orientation."""
+    init = model.initializers
+    consumers: Dict[str, List[OnnxNode]] = {}
+    for n in model.nodes:
+        for i in n.inputs:
+            consumers.setdefault(i, []).append(n)
+    out: Dict[str, np.ndarray] = {k: v for k, v in init.items() if not k.startswith("onnx::") and not k.startswith("/")}
+    for n in model.nodes:
+        if n.op_type == "MatMul" and len(n.inputs) == 2 and n.inputs[1] in init and n.inputs[1].startswith("onnx::"):
+            w = init[n.inputs[1]]
+            for c in consumers.get(n.outputs[0], []):
+                if c.op_type == "Add":
+                    b = [i for i in c.inputs if i in init and i.endswith(".bias")]
+                    if b:
+                        out[b[0][: -len(".bias")] + ".weight"] = np.ascontiguousarray(w.T)
+                        break
+        elif n.op_type == "Gemm" and len(n.inputs) >= 2 and n.inputs[1] in init:
+            w = init[n.inputs[1]]
+            if n.inputs[1].startswith("onnx::") and len(n.inputs) == 3 and n.inputs[2].endswith(".bias"):
+                out[n.inputs[2][: -len(".bias")] + ".weight"] = np.ascontiguousarray(w if n.attrs.get("transB", 0) else w.T)
+    return out
+
+
+def summarize(model: OnnxModel) -> Dict[str, object]:
+    ops: Dict[str, int] = {}
+    for n in model.nodes:
+        ops[n.op_type] = ops.get(n.op_type, 0) + 1
+    return {"graph": model.graph_name, "producer": model.producer, "opset": model.opset, "ops": dict(sorted(ops.items())),
+            "inputs": [(v.name, v.elem_type, v.shape) for v in model.inputs],
+            "outputs": [(v.name, v.elem_type, v.shape) for v in model.outputs],
+            "n_initializers": len(model.initializers), "n_params": int(sum(a.size for a in model.initializers.values()))}
+
+
+# this build's name <- exporter name (public F5-TTS DiT / HiFi-GAN generator module naming).  {n},{i},{j},{k} = indices.
+NAME_RULES: List[Tuple[str, str]] = [
+    (r"text\.embed\.weight", "transformer.text_embed.text_embed.weight"),
+    (r"text\.blocks\.(\d+)\.(dwconv|norm|pwconv1|pwconv2)\.(weight|bias)", "transformer.text_embed.text_blocks.{0}.{1}.{2}"),
+    (r"text\.blocks\.(\d+)\.grn\.(gamma|beta)", "transformer.text_embed.text_blocks.{0}.grn.{1}"),
+    (r"input\.proj\.(weight|bias)", "transformer.input_embed.proj.{0}"),
+    (r"input\.pos_conv1\.(weight|bias)", "transformer.input_embed.conv_pos_embed.conv1d.0.{0}"),
+    (r"input\.pos_conv2\.(weight|bias)", "transformer.input_embed.conv_pos_embed.conv1d.2.{0}"),
+    (r"time\.mlp1\.(weight|bias)", "transformer.time_embed.time_mlp.0.{0}"),
+    (r"time\.mlp2\.(weight|bias)", "transformer.time_embed.time_mlp.2.{0}"),
+    (r"blocks\.(\d+)\.adaln\.(weight|bias)", "transformer.transformer_blocks.{0}.attn_norm.linear.{1}"),
+    (r"blocks\.(\d+)\.attn\.out\.(weight|bias)", "transformer.transformer_blocks.{0}.attn.to_out.0.{1}"),
+    (r"blocks\.(\d+)\.ff1\.(weight|bias)", "transformer.transformer_blocks.{0}.ff.ff.0.0.{1}"),
+    (r"blocks\.(\d+)\.ff2\.(weight|bias)", "transformer.transformer_blocks.{0}.ff.ff.2.{1}"),
+    (r"final\.adaln\.(weight|bias)", "transformer.norm_out.linear.{0}"),
+    (r"final\.proj\.(weight|bias)", "transformer.proj_out.{0}"),
+    (r"voc\.pre\.(weight|bias)", "conv_pre.{0}"),
+    (r"voc\.up\.(\d+)\.(weight|bias)", "ups.{0}.{1}"),
+    (r"voc\.post\.(weight|bias)", "conv_post.{0}"),
+]
+_QKV = re.compile(r"blocks\.(\d+)\.attn\.qkv\.(weight|bias)")
+_RES = re.compile(r"voc\.res\.(\d+)\.(\d+)\.(\d+)\.conv([12])\.(weight|bias)")
+
+
+def exporter_names(name: str, n_res_kernels: int) -> List[str]:
+    """The exporter-side tensor(s) one of this build's weights is assembled from (several = concatenated on dim 0)."""
+    m = _QKV.fullmatch(name)
+    if m:
+        return [f"transformer.transformer_blocks.{m[1]}.attn.to_{p}.{m[2]}" for p in "qkv"]
+    m = _RES.fullmatch(name)
+    if m:
+        return [f"resblocks.{int(m[1]) * n_res_kernels + int(m[2])}.convs{m[4]}.{m[3]}.{m[5]}"]
+    for pat, tmpl in NAME_RULES:
+        m = re.fullmatch(pat, name)
+        if m:
+            return [tmpl.format(*m.groups())]
+    raise KeyError(name)
+
+
+def infer_spec(named: Dict[str, np.ndarray], decode_nodes: List[OnnxNode], base=None):
+    """Architecture constants read off the graphs: widths and kernel sizes from tensor shapes, depths by counting blocks,
+    up-sampling rates / kernels from the ConvTranspose nodes' attributes, dilations from the Conv nodes' attributes.
+    What shapes cannot tell (heads vs head_dim split, cfg strength, sway coefficient, rope base) stays at ``base``."""
+    from .model_spec import ModelSpec
+    base = base or ModelSpec.full()
+    g = named
+
+    def need(k):
+        if k not in g:
+            raise UnsupportedGraph(f"expected initializer {k!r} is missing; found e.g. {sorted(g)[:8]}")
+        return g[k]
+
+    def count(fmt):
+        n = 0
+        while fmt.format(n) in g:
+            n += 1
+        return n
+
+    emb = need("transformer.text_embed.text_embed.weight")
+    dim = need("transformer.proj_out.weight").shape[1]
+    n_mel = need("transformer.proj_out.weight").shape[0]
+    depth = count("transformer.transformer_blocks.{}.attn.to_q.weight")
+    text_layers = count("transformer.text_embed.text_blocks.{}.dwconv.weight")
+    pos = need("transformer.input_embed.conv_pos_embed.conv1d.0.weight")
+    ups = [n for n in decode_nodes if n.op_type == "ConvTranspose"]
+    if not ups:
+        ops = sorted({n.op_type for n in decode_nodes})
+        raise UnsupportedGraph("decode graph has no ConvTranspose nodes: not the transposed-conv / MRF generator this build "
+                               f"implements (ops present: {ops})")
+    rates = tuple(int(n.attrs["strides"][0]) for n in ups)
+    kernels = tuple(int(g[n.inputs[1]].shape[2]) for n in ups)
+    n_stage = len(ups)
+    n_resblocks = count("resblocks.{}.convs1.0.weight")
+    if n_resblocks % n_stage:
+        raise UnsupportedGraph(f"{n_resblocks} resblocks do not divide into {n_stage} up-sampling stages")
+    n_k = n_resblocks // n_stage
+    res_k = tuple(int(g[f"resblocks.{j}.convs1.0.weight"].shape[2]) for j in range(n_k))
+    n_d = count("resblocks.0.convs1.{}.weight")
+    by_weight = {n.inputs[1]: n for n in decode_nodes if n.op_type == "Conv" and len(n.inputs) > 1}
+    dil = tuple(int(by_weight[f"resblocks.0.convs1.{k}.weight"].attrs.get("dilations", [1])[0]) for k in range(n_d))
+    head_dim = base.head_dim if dim % base.head_dim == 0 else dim
+    ff1 = need("transformer.transformer_blocks.0.ff.ff.0.0.weight")
+    t1 = need("transformer.time_embed.time_mlp.0.weight")
+    pw1 = need("transformer.text_embed.text_blocks.0.pwconv1.weight") if text_layers else None
+    from dataclasses import replace
+    return replace(base, n_mel=int(n_mel), dim=int(dim), depth=depth, heads=dim // head_dim, head_dim=head_dim,
+                   ff_mult=int(ff1.shape[0] // dim), text_dim=int(emb.shape[1]), text_layers=text_layers,
+                   text_conv_k=int(g["transformer.text_embed.text_blocks.0.dwconv.weight"].shape[2]) if text_layers else base.text_conv_k,
+                   text_ff_mult=int(pw1.shape[0] // emb.shape[1]) if text_layers else base.text_ff_mult,
+                   vocab_size=int(emb.shape[0]) - 1, pos_conv_k=int(pos.shape[2]), pos_conv_groups=int(dim // pos.shape[1]),
+                   time_freq_dim=int(t1.shape[1]), voc_pre_ch=int(need("conv_pre.weight").shape[0]),
+                   voc_pre_k=int(g["conv_pre.weight"].shape[2]), voc_post_k=int(need("conv_post.weight").shape[2]),
+                   voc_up_rates=rates, voc_up_kernels=kernels, voc_res_kernels=res_k, voc_res_dilations=dil)
+
+
+def import_graphs(pre: OnnxModel, tr: OnnxModel, dec: OnnxModel, base=None):
+    """-> (ModelSpec, {this build's name: torch fp32 tensor in torch-native layout})."""
+    import torch
+    from .model_spec import weight_shapes
+    named: Dict[str, np.ndarray] = {}
+    for m in (pre, tr, dec):
+        named.update(recover_names(m))
+    spec = infer_spec(named, dec.nodes, base)
+    weights = {}
+    for name, (shape, _scale) in weight_shapes(spec).items():
+        srcs = exporter_names(name, len(spec.voc_res_kernels))
+        missing = [s for s in srcs if s not in named]
+        if missing:
+            raise UnsupportedGraph(f"{name}: initializer(s) {missing} not found in the ONNX graphs")
+        arr = np.concatenate([named[s] for s in srcs], axis=0) if len(srcs) > 1 else named[srcs[0]]
+        arr = np.asarray(arr, dtype=np.float32)
+        if arr.size != int(np.prod(shape)):
+            raise UnsupportedGraph(f"{name}: ONNX tensor(s) {srcs} have shape {arr.shape}, this build expects {shape}")
+        weights[name] = torch.from_numpy(np.array(arr.reshape(shape), dtype=np.float32, order="C", copy=True))        # e.g. GRN gamma (1,1,C) -> (C,)
+    return spec, weights
+
+
+def import_archive(tar: tarfile.TarFile, base=None):
+    """The reference's archive layout (core/model.py:73-110): members are matched by suffix, as the reference does."""
+    names = tar.getnames()
+    models = {}
+    for key in ("preprocess", "transformer", "decode"):
+        member = next((m for m in names if m.endswith(key + ".onnx")), None)
+        if not member:
+            raise FileNotFoundError(f"Model file '{key}.onnx' not found in model archive")
+        models[key] = parse_model(tar.extractfile(member).read())
+    return import_graphs(models["preprocess"], models["transformer"], models["decode"], base)
+
+
+# ------------------------------------------------------------------ export (inverse mapping; fixture maker)
+def export_archive_members(spec, weights, storage: str = "raw") -> Dict[str, bytes]:
+    """This build's weights as three ONNX files with exporter-style structure: Linear = MatMul(x, onnx::MatMul_n [in,out]) +
+    Add(bias name kept); Conv / ConvTranspose keep parameter names and carry kernel_shape / strides / dilations / group
+    attributes.  The node lists are a structural skeleton (enough to recover names and constants), not a runnable graph."""
+    n_k = len(spec.voc_res_kernels)
+    files = {"preprocess": ([], []), "transformer": ([], []), "decode": ([], [])}
+    anon = [0]
+
+    def where(name):
+        return "decode" if name.startswith("voc.") else ("preprocess" if name.startswith("text.") else "transformer")
+
+    def linear(dst, ename, w, b):
+        nodes, inits = files[dst]
+        anon[0] += 1
+        wn = f"onnx::MatMul_{1000 + anon[0]}"
+        stem = ename[: -len(".weight")]
+        inits.append((wn, np.ascontiguousarray(w.T), storage))
+        inits.append((stem + ".bias", b, storage))
+        nodes.append(OnnxNode("MatMul", f"/{stem}/MatMul", [f"/{stem}/in", wn], [f"/{stem}/MatMul_output_0"]))
+        nodes.append(OnnxNode("Add", f"/{stem}/Add", [stem + ".bias", f"/{stem}/MatMul_output_0"], [f"/{stem}/Add_output_0"]))
+
+    w = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in weights.items()}
+    done = set()
+    for name in w:
+        if name in done or name.endswith(".bias"):
+            continue
+        dst = where(name)
+        nodes, inits = files[dst]
+        if _QKV.fullmatch(name):
+            bias = name[: -len("weight")] + "bias"
+            for part, ename, bname in zip(np.split(w[name], 3, axis=0), exporter_names(name, n_k), exporter_names(bias, n_k)):
+                idx = "qkv".index(ename.split(".to_")[1][0])
+                linear(dst, ename, part, np.split(w[bias], 3)[idx])
+            done |= {name, bias}
+            continue
+        ename = exporter_names(name, n_k)[0]
+        arr = w[name]
+        if name.endswith(".grn.gamma") or name.endswith(".grn.beta"):
+            inits.append((ename, arr.reshape(1, 1, -1), storage))
+        elif name == "text.embed.weight":
+            inits.append((ename, arr, storage))
+            nodes.append(OnnxNode("Gather", "/text_embed/Gather", [ename, "text_ids"], ["/text_embed/Gather_output_0"]))
+        elif arr.ndim == 2:
+            linear(dst, ename, arr, w[name[: -len("weight")] + "bias"])
+            done.add(name[: -len("weight")] + "bias")
+        elif arr.ndim == 3:
+            bias = name[: -len("weight")] + "bias"
+            bname = exporter_names(bias, n_k)[0]
+            inits.append((ename, arr, storage))
+            inits.append((bname, w[bias], storage))
+            done.add(bias)
+            attrs: Dict[str, object] = {"kernel_shape": [int(arr.shape[2])]}
+            op = "Conv"
+            m = _RES.fullmatch(name)
+            if name.startswith("voc.up."):
+                op = "ConvTranspose"
+                i = int(name.split(".")[2])
+                attrs.update(strides=[int(spec.voc_up_rates[i])], pads=[(arr.shape[2] - spec.voc_up_rates[i]) // 2] * 2, group=1, dilations=[1])
+            elif m:
+                d = spec.voc_res_dilations[int(m[3])] if m[4] == "1" else 1
+                attrs.update(dilations=[int(d)], strides=[1], pads=[d * (arr.shape[2] - 1) // 2] * 2, group=1)
+            elif name.startswith("input.pos_conv"):
+                attrs.update(group=int(spec.pos_conv_groups), dilations=[1], strides=[1], pads=[arr.shape[2] // 2] * 2)
+            elif ".dwconv." in name:
+                attrs.update(group=int(arr.shape[0]), dilations=[1], strides=[1], pads=[arr.shape[2] // 2] * 2)
+            else:
+                attrs.update(group=1, dilations=[1], strides=[1], pads=[arr.shape[2] // 2] * 2)
+            stem = ename[: -len(".weight")]
+            nodes.append(OnnxNode(op, f"/{stem}/{op}", [f"/{stem}/in", ename, bname], [f"/{stem}/{op}_output_0"], attrs))
+        else:                                                     # 1-D named parameters (LayerNorm weight)
+            inits.append((ename, arr, storage))
+        done.add(name)
+    for name in w:                                                # biases of non-linear / non-conv parameters (LayerNorm bias)
+        if name not in done:
+            files[where(name)][1].append((exporter_names(name, n_k)[0], w[name], storage))
+    io_ = {"preprocess": ([OnnxValue("audio", 5, (1, 1, "audio_len")), OnnxValue("text_ids", 6, (1, "text_len")), OnnxValue("max_duration", 7, (1,))],
+                          [OnnxValue("noise", 1, (1, "max_duration", spec.n_mel))]),
+           "transformer": ([OnnxValue("noise", 1, (1, "max_duration", spec.n_mel)), OnnxValue("time_step", 6, (1,))],
+                           [OnnxValue("denoised", 1, (1, "max_duration", spec.n_mel)), OnnxValue("time_step_out", 6, (1,))]),
+           "decode": ([OnnxValue("denoised", 1, (1, "max_duration", spec.n_mel)), OnnxValue("ref_signal_len", 7, (1,))],
+                      [OnnxValue("generated_signal", 5, (1, 1, "out_len"))])}
+    return {k + ".onnx": encode_model(files[k][0], files[k][1], io_[k][0], io_[k][1], graph_name="main_graph") for k in files}
+
+
+def write_onnx_archive(path: str, spec, weights, extra_members: Optional[Dict[str, bytes]] = None, storage: str = "raw") -> None:
+    members = dict(export_archive_members(spec, weights, storage))
+    members.update(extra_members or {})
+    with tarfile.open(path, "w") as tar:
+        for name, data in members.items():
+            info = tarfile.TarInfo(name)
+            info.size = len(data)
+            tar.addfile(info, io.BytesIO(data))
