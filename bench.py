@@ -77,21 +77,25 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
     gen_frames = torch.minimum(gen_frames, 1875 - ref_frames)                            # 20 s chunk cap of the reference
     frames = (ref_frames + gen_frames).tolist()
     mine = sharding.shard_units([sharding.unit_cost(f, spec.dim) for f in frames], world)[rank]
-    B = len(mine)
-    S, T = int(samples[mine].max()), int(toks[mine].max())
-    audio = torch.zeros(B, S, dtype=torch.int16)
-    ids = torch.zeros(B, T, dtype=torch.int32)
-    for j, u in enumerate(mine):
-        audio[j, : int(samples[u])] = synth_reference_clip(1000 + u, int(samples[u]))
-        ids[j, : int(toks[u])] = torch.randint(1, spec.vocab_size, (int(toks[u]),), generator=g, dtype=torch.int32)
-    seq = torch.tensor([frames[u] for u in mine], dtype=torch.int32)
-    N = int(seq.max())
-    noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
-    d = dict(audio=audio.to(device), audio_len=samples[mine].to(torch.int32).to(device), ids=ids.to(device),
-             text_len=toks[mine].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
-    t_gen_max = int(gen_frames[mine].max())
+    batches = []
+    for grp in sharding.plan_batches([frames[u] for u in mine], per_rank, pad_frac=0.05, min_units=4):     # length buckets: less padding
+        units = [mine[j] for j in grp]
+        B = len(units)
+        S, T = int(samples[units].max()), int(toks[units].max())
+        audio = torch.zeros(B, S, dtype=torch.int16)
+        ids = torch.zeros(B, T, dtype=torch.int32)
+        for j, u in enumerate(units):
+            audio[j, : int(samples[u])] = synth_reference_clip(1000 + u, int(samples[u]))
+            ids[j, : int(toks[u])] = torch.randint(1, spec.vocab_size, (int(toks[u]),), generator=g, dtype=torch.int32)
+        seq = torch.tensor([frames[u] for u in units], dtype=torch.int32)
+        N = int(seq.max())
+        noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
+        d = dict(audio=audio.to(device), audio_len=samples[units].to(torch.int32).to(device), ids=ids.to(device),
+                 text_len=toks[units].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
+        batches.append((d, N, int(gen_frames[units].max())))
     audio_s = float(gen_frames[mine].sum()) * spec.hop_length / spec.sample_rate
-    return d, N, t_gen_max, audio_s, B
+    fill = float(sum(frames[u] for u in mine)) / sum(b[0]["seq_len"].numel() * b[1] for b in batches)
+    return batches, audio_s, len(mine), fill
 
 
 def longform(a):
@@ -208,13 +212,15 @@ def main():
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
     if a.workload == "mixed256":
-        d, N, t_gen, audio_s_rank, nb = make_mixed_inputs(spec, a.batch, rank, world, device)
+        batches, audio_s_rank, nb, fill = make_mixed_inputs(spec, a.batch, rank, world, device)
     else:
         d, N = make_inputs(spec, a.batch, rank, device)
-        t_gen, audio_s_rank, nb = GEN_FRAMES, a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch
+        batches, audio_s_rank, nb, fill = [(d, N, GEN_FRAMES)], a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch, 1.0
 
     def step():
-        return eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen)
+        outs = [eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen)
+                for d, N, t_gen in batches]
+        return outs
 
     for _ in range(a.warmup):
         step()
@@ -232,8 +238,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    pcm_len = out[2]
-    assert abs(float(pcm_len.sum().item()) / spec.sample_rate - audio_s_rank) < 1e-3
+    assert abs(sum(float(o[2].sum().item()) for o in out) / spec.sample_rate - audio_s_rank) < 1e-3
     if dist is not None:                                  # total audio over all ranks (ragged shards differ)
         ta = torch.tensor([audio_s_rank], dtype=torch.float64, device=device)
         dist.all_reduce(ta, op=dist.ReduceOp.SUM)
@@ -285,7 +290,8 @@ def main():
         "rtf": round(elapsed / total_audio, 6),
         "config": {"workload": (f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
                                 if a.workload == "batch32" else
-                                f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips, N_max={N}), ")
+                                f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips) in "
+                                f"{len(batches)} length-bucketed batches {[b[0]['seq_len'].numel() for b in batches]} (row fill {fill:.3f}), ")
                                + f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
         "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,

@@ -143,6 +143,8 @@ typedef struct vv_ln_args {
     float eps;
     const void* delta;      /* optional [R][ld_delta]: x += delta first (x is then updated in place) */
     int32_t delta_dtype, ld_delta;
+    const void* delta2;     /* optional second delta (same dtype / ld): y = LN((x + delta) + delta2) */
+    int32_t keep_x;         /* 1: normalise x + delta but leave x as it is (the caller adds this delta again later, with delta2) */
 } vv_ln_args;
 int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
 

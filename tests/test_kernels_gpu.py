@@ -235,6 +235,20 @@ def test_layernorm_modulate(hip_tiny, D, out_dtype):
         xn = x + dlt.float()
         assert torch.equal(xx.cpu(), xn)
         assert gu.rel_err(y, F.layer_norm(xn, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
+        # once-per-block protocol: keep_x normalises x + d1 without touching x; the later call stores (x + d1) + d2
+        d2 = (torch.randn(R, D, generator=g) * 0.5).to(ddt)
+        xx, dd2 = x.clone().to(gu.DEV), d2.to(gu.DEV)
+        a.x, a.keep_x = xx.data_ptr(), 1
+        gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(xx.cpu(), x)
+        assert gu.rel_err(y, F.layer_norm(xn, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
+        a.delta2, a.keep_x = dd2.data_ptr(), 0
+        gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        xn2 = (x + dlt.float()) + d2.float()
+        assert torch.equal(xx.cpu(), xn2)
+        assert gu.rel_err(y, F.layer_norm(xn2, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
 
 
 # ------------------------------------------------------------------------------------ conv position embedding

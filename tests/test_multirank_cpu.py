@@ -64,3 +64,22 @@ def test_shard_units_properties():
     assert all(len(s) == 8 for s in eq) and sorted(sum(eq, [])) == list(range(64))
     one = sharding.shard_units([3.0, 1.0, 2.0], 1)
     assert one == [[0, 1, 2]]
+
+
+def test_plan_batches_covers_units_and_bounds_padding():
+    from vietvoice_tts_amd.sharding import plan_batches
+    import random
+    rnd = random.Random(3)
+    for trial in range(50):
+        n = rnd.randint(1, 70)
+        frames = [rnd.randint(90, 1875) for _ in range(n)]
+        mx = rnd.choice([1, 4, 8, 32])
+        out = plan_batches(frames, mx, pad_frac=0.05, min_units=4)
+        assert sorted(i for b in out for i in b) == list(range(n))                 # every unit exactly once
+        assert all(1 <= len(b) <= mx for b in out)
+        for b in out[:-1]:                                                           # closed batches respect the padding bound (or are at min size)
+            n_max = max(frames[i] for i in b)
+            waste = 1 - sum(frames[i] for i in b) / (len(b) * n_max)
+            assert waste <= 0.05 + 1e-9 or len(b) <= 4 or len(b) == mx
+    assert plan_batches([], 8) == [] and plan_batches([100], 8) == [[0]]
+    assert plan_batches([1600] * 32, 32) == [list(range(32))]                       # the headline workload stays one batch

@@ -11,7 +11,8 @@ dev = "cuda:0"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 102400
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 g = torch.Generator().manual_seed(0)
-for K in (256, 512, 1024, 2048, 4096):
+KS = [int(k) for k in sys.argv[3].split(',')] if len(sys.argv) > 3 else (256, 512, 1024, 2048, 4096)
+for K in KS:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
     out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)

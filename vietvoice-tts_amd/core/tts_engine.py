@@ -145,10 +145,15 @@ class TTSEngine:
         dev = eng.device
         eng.set_nfe(self.config.nfe_step)
         hop = self.config.hop_length
-        waves: List[np.ndarray] = []
-        step = max(1, int(self.config.max_batch_chunks))
-        for lo in range(0, len(inputs_list), step):
-            group = inputs_list[lo: lo + step]
+        from ..sharding import plan_batches
+        n_items = len(inputs_list)
+        seq_all = [int(g[2][0]) for g in inputs_list]
+        if noise_blocks is None:      # the same seeded stream the session path draws from: one (N_i, n_mel) block per chunk, in item order
+            noise_blocks = [torch.randn((n, spec.n_mel), generator=m.noise_gen, dtype=torch.float32) for n in seq_all]
+        waves: List[Optional[np.ndarray]] = [None] * n_items
+        # length-bucketed ragged batches: every kernel but attention pays for B x N_max rows, so similar lengths ride together
+        for idx in plan_batches(seq_all, max(1, int(self.config.max_batch_chunks)), pad_frac=0.05, min_units=4):
+            group = [inputs_list[i] for i in idx]
             B = len(group)
             lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)
             lens_t = np.array([g[1].shape[1] for g in group], dtype=np.int32)
@@ -166,7 +171,7 @@ class TTSEngine:
                 for i, g in enumerate(group):
                     audio_np[i, : lens_a[i]] = g[0].reshape(-1)
                 audio = torch.from_numpy(audio_np).to(dev)
-            seq = np.array([int(g[2][0]) for g in group], dtype=np.int32)
+            seq = np.array([seq_all[i] for i in idx], dtype=np.int32)
             ref_frames = lens_a // hop + 1
             N = int(seq.max())
             t_gen = int((seq - ref_frames).max())
@@ -174,11 +179,9 @@ class TTSEngine:
                 # fixed frame buckets (multiples of 128) so that one captured vocoder graph serves every chunk group
                 N = (N + 127) // 128 * 128
                 t_gen = N - int(ref_frames.min())
-            # the same seeded stream the session path draws from, one (N_i, n_mel) block per chunk in order
             noise = torch.zeros((B, N, spec.n_mel), dtype=torch.float32)
-            for i in range(B):
-                noise[i, : seq[i]] = (noise_blocks[lo + i] if noise_blocks is not None else
-                                      torch.randn((int(seq[i]), spec.n_mel), generator=m.noise_gen, dtype=torch.float32))
+            for i, j in enumerate(idx):
+                noise[i, : seq[i]] = noise_blocks[j]
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
             if self.config.use_hip_graph:
                 pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N)
@@ -191,8 +194,8 @@ class TTSEngine:
             else:
                 _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen)
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
-            for i in range(B):
-                waves.append(pcm[i, : pcm_len[i]].reshape(1, 1, -1))
+            for i, j in enumerate(idx):
+                waves[j] = pcm[i, : pcm_len[i]].reshape(1, 1, -1)
         return waves
 
     # ------------------------------------------------------------------ public API

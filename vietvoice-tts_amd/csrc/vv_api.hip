@@ -367,12 +367,13 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     if (R > (size_t)1 << 30) return c->fail(-22, "batch too large");
     const int S = c->n_steps;
     Need nd;
-    nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
+    nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
     nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64);
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
     char* h2 = carve<char>(c, es * R * D);
+    char* h3 = carve<char>(c, es * R * D);
     float* xres = carve<float>(c, R * D);
     char* qkv = carve<char>(c, es * R * 3 * D);
     char* att = carve<char>(c, es * R * D);
@@ -410,8 +411,10 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
             KCHK(c, vvk_posconv(&a, st, &m__));
         }
-        // Residual stream protocol: a branch GEMM writes delta = gate * (out + bias) (operand dtype) into h2 and the NEXT
-        // LayerNorm kernel performs x += delta while it streams x anyway (no read-modify-write in a GEMM epilogue).
+        // Residual stream protocol: a branch GEMM writes delta = gate * (out + bias) (operand dtype) and a LayerNorm kernel adds
+        // it while it streams x anyway (no read-modify-write in a GEMM epilogue).  x is REWRITTEN ONCE PER BLOCK: the norm
+        // before the MLP normalises x + d_attn without storing it (keep_x), the next block's first norm stores
+        // (x + d_attn) + d_mlp -- the same additions in the same order, a third fewer bytes written by the norm kernels.
         bool pending = false;
         for (int l = 0; l < g.depth; ++l) {
             const float* mod = c->modtab + ((size_t)l * S + s) * 6 * D;
@@ -421,8 +424,8 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
             a.delta_dtype = c->dt; a.ld_delta = D;
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
-            a.delta = pending ? h2 : nullptr;
-            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
+            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
@@ -432,18 +435,19 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D)) return r;
             a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
-            a.delta = h2;
-            { Prof p(c, VV_PROF_NORM, 0, 2 * (4.0 + es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+            a.delta = h2; a.delta2 = nullptr; a.keep_x = 1;
+            { Prof p(c, VV_PROF_NORM, 0, (4.0 + 2.0 * es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h2, D, (int)R, D, FF, st, mod + 5 * D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h3, D, (int)R, D, FF, st, mod + 5 * D)) return r;
             pending = true;
         }
         {
             const float* fm = c->fintab + (size_t)s * 2 * D;
             vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
             a.w = fm; a.b = fm + D;                          // scale, shift
-            a.delta = pending ? h2 : nullptr; a.delta_dtype = c->dt; a.ld_delta = D;
-            Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + es) * R * D : 0), st);
+            a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 1;     // x is re-initialised by the next step
+            a.delta_dtype = c->dt; a.ld_delta = D;
+            Prof p(c, VV_PROF_NORM, 0, es * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 4.0 * R * D), st);
             KCHK(c, vvk_ln_mod(&a, st, &m__));
         }
         if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, h, D, "final.proj.weight", D, "final.proj.bias", pred, MP, (int)R, MP, D, st,

@@ -15,7 +15,8 @@ template <typename To, typename Td>
 __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int ldx, To* __restrict__ y, int ldy,
                                                      int R, int D, const float* __restrict__ w,
                                                      const float* __restrict__ b, int add_one, float eps,
-                                                     const Td* __restrict__ delta, int ldd) {
+                                                     const Td* __restrict__ delta, int ldd, const Td* __restrict__ delta2,
+                                                     int keep_x) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -31,7 +32,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
             if (delta) {
                 const float4 d = load4<Td>(delta + (size_t)row * ldd + c * 4);
                 v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
-                *(float4*)(xr + c * 4) = v[i];
+                if (delta2) {                                // (x + delta) + delta2: the order the one-delta-at-a-time protocol adds in
+                    const float4 d2 = load4<Td>(delta2 + (size_t)row * ldd + c * 4);
+                    v[i].x += d2.x; v[i].y += d2.y; v[i].z += d2.z; v[i].w += d2.w;
+                }
+                if (!keep_x) *(float4*)(xr + c * 4) = v[i];
             }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
@@ -322,7 +327,7 @@ int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
     const int grid = (a->R + 3) / 4;
     float* x = const_cast<float*>(a->x);
     const bool ob = a->out_dtype == VV_BF16, db = a->delta_dtype == VV_BF16;
-#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta)
+#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta, (const Td*)a->delta2, a->keep_x)
     if (ob && db) LN_GO(bf16, bf16);
     else if (ob) LN_GO(bf16, float);
     else if (db) LN_GO(float, bf16);

@@ -61,7 +61,8 @@ class vv_attn_args(C.Structure):
 class vv_ln_args(C.Structure):
     _fields_ = [("out_dtype", C.c_int32), ("x", C.c_void_p), ("ldx", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("D", C.c_int32), ("w", C.c_void_p), ("b", C.c_void_p), ("add_one", C.c_int32), ("eps", C.c_float),
-                ("delta", C.c_void_p), ("delta_dtype", C.c_int32), ("ld_delta", C.c_int32)]
+                ("delta", C.c_void_p), ("delta_dtype", C.c_int32), ("ld_delta", C.c_int32),
+                ("delta2", C.c_void_p), ("keep_x", C.c_int32)]
 
 
 class vv_posconv_args(C.Structure):

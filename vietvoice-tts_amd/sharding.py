@@ -30,6 +30,33 @@ def shard_units(costs: Sequence[float], world: int) -> List[List[int]]:
     return out
 
 
+def plan_batches(frames: Sequence[int], max_units: int, pad_frac: float = 0.08, min_units: int = 8) -> List[List[int]]:
+    """Length-bucketed GPU batches for ragged units.  Every kernel except attention works on B x N_max rows, so a batch
+    pays for its padding; units are sorted by frames and cut into batches of at most ``max_units`` such that the padded
+    share of a batch stays below ``pad_frac`` once it holds ``min_units`` (small batches under-fill the GEMM tiles).
+    Returns lists of unit indices, longest batch first; every unit appears exactly once."""
+    order = sorted(range(len(frames)), key=lambda i: (-int(frames[i]), i))
+    out: List[List[int]] = []
+    cur: List[int] = []
+    tot = 0
+    for i in order:
+        f = int(frames[i])
+        if cur:
+            n_max = int(frames[cur[0]])
+            waste = 1.0 - (tot + f) / float((len(cur) + 1) * n_max)
+            if len(cur) >= max_units or (len(cur) >= min_units and waste > pad_frac):
+                out.append(cur)
+                cur, tot = [], 0
+        cur.append(i)
+        tot += f
+    if cur:
+        if out and len(cur) < min_units and len(out[-1]) + len(cur) <= max_units:
+            out[-1].extend(cur)                  # a short tail rides with the previous batch rather than alone
+        else:
+            out.append(cur)
+    return out
+
+
 def unit_cost(frames: int, dim: int = 1024) -> float:
     return float(frames) * (8.0 * dim * dim + 2.0 * frames * dim)
 
