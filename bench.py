@@ -78,7 +78,8 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
     frames = (ref_frames + gen_frames).tolist()
     mine = sharding.shard_units([sharding.unit_cost(f, spec.dim) for f in frames], world)[rank]
     batches = []
-    for grp in sharding.plan_batches([frames[u] for u in mine], per_rank, pad_frac=0.05, min_units=4):     # length buckets: less padding
+    pad_frac = float(os.environ.get("VV_BENCH_PAD_FRAC", "1.0"))     # 1.0 = one ragged batch per rank (rows are packed on the device)
+    for grp in sharding.plan_batches([frames[u] for u in mine], per_rank, pad_frac=pad_frac, min_units=4):
         units = [mine[j] for j in grp]
         B = len(units)
         S, T = int(samples[units].max()), int(toks[units].max())
@@ -92,6 +93,7 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
         noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
         d = dict(audio=audio.to(device), audio_len=samples[units].to(torch.int32).to(device), ids=ids.to(device),
                  text_len=toks[units].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
+        d["gen_frames"] = [int(gen_frames[u]) for u in units]
         batches.append((d, N, int(gen_frames[units].max())))
     audio_s = float(gen_frames[mine].sum()) * spec.hop_length / spec.sample_rate
     fill = float(sum(frames[u] for u in mine)) / sum(b[0]["seq_len"].numel() * b[1] for b in batches)
@@ -218,7 +220,8 @@ def main():
         batches, audio_s_rank, nb, fill = [(d, N, GEN_FRAMES)], a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch, 1.0
 
     def step():
-        outs = [eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen)
+        outs = [eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen,
+                                     gen_frames=d.get("gen_frames"))
                 for d, N, t_gen in batches]
         return outs
 

@@ -121,6 +121,7 @@ typedef struct vv_gemm_args {
     int32_t n_store, seq_n, rope_dim;
     const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
     int32_t tile;   /* 0 = auto (256x256 tile when M >= 4096 and N % 256 == 0), 128 or 256 to force */
+    const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
 } vv_gemm_args;
 int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 
@@ -130,6 +131,8 @@ typedef struct vv_attn_args {
     void* out; int32_t ld_out;
     int32_t n_seq, seq_n, heads, dim;
     const int32_t* kv_len;
+    const int32_t* row_start;  /* optional [n_seq]: packed ragged rows -- sequence s owns rows [row_start[s], +kv_len[s]);
+                                  default s * seq_n (padded layout, rows beyond kv_len are computed and ignored) */
 } vv_attn_args;
 int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
 
@@ -157,6 +160,7 @@ typedef struct vv_posconv_args {
     const void* resid; int32_t ld_resid;   /* optional, operand dtype */
     int32_t n_seq, seq_n, groups, KW, B;
     const int32_t* seq_len;
+    const int32_t* row_start;  /* optional [n_seq]: packed ragged rows, as in vv_attn_args */
 } vv_posconv_args;
 int vv_posconv(vv_ctx* ctx, const vv_posconv_args* args, void* stream);
 

@@ -136,6 +136,85 @@ def test_gemm_big_tile(hip_tiny, dtype, M, N, K):
     assert gu.rel_err(dl, gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=3, gate=gate.to(gu.DEV), tile=128).float()) < (8e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
+# ------------------------------------------------------------------------------------ packed ragged rows
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_rows_rope_attention_posconv(hip_tiny, dtype, tiny_setup):
+    """Ragged sequences stored back to back (row_start / rope_pos): the QKV rope epilogue, attention and the conv position
+    embedding must give, per sequence, what the padded layout gives -- and must not touch a neighbour's rows."""
+    rt, gu = _imports()
+    from oracle.vv_oracle import Oracle
+    spec, _, orc = tiny_setup
+    eng = hip_tiny["f32"]
+    lens = [150, 1, 97, 129, 300]
+    D, heads, G, KW = 128, 2, 2, 31
+    starts = [0]
+    for L in lens:
+        starts.append(starts[-1] + L)
+    R, N = starts[-1], max(lens)
+    g = torch.Generator().manual_seed(23)
+    rs = torch.tensor(starts[:-1], dtype=torch.int32, device=gu.DEV)
+    sl = torch.tensor(lens, dtype=torch.int32, device=gu.DEV)
+    pos = torch.cat([torch.arange(L) for L in lens]).to(torch.int32)
+    tol = _tol(dtype)
+    # --- QKV GEMM + rope at per-row positions (forced 256 tile exercises the persistent kernel's lookup in bf16)
+    Dg = 256                                                       # 3 * Dg is a multiple of the 256 tile
+    A = torch.randn(R, Dg, generator=g).to(dtype)
+    W = (torch.randn(3 * Dg, Dg, generator=g) / math.sqrt(Dg)).to(dtype)
+    b = torch.randn(3 * Dg, generator=g) * 0.1
+    ropes = orc.rope_tables(N)
+    y = A.float() @ W.float().t() + b
+    q, k, v = y.split(Dg, dim=-1)
+    tabs = [t[pos.long()] for t in ropes]
+    ref = torch.cat([Oracle.rope_apply(q.reshape(R, Dg // 64, 64), tabs[0], tabs[1]).reshape(R, Dg),
+                     Oracle.rope_apply(k.reshape(R, Dg // 64, 64), tabs[2], tabs[3]).reshape(R, Dg), v], dim=-1)
+    dr = [t.contiguous().to(gu.DEV) for t in ropes]
+    cs = [torch.zeros(N, 64, device=gu.DEV) for _ in range(2)]
+    for i in range(2):
+        gu.check(eng, eng.lib.vv_rope_compact(eng.ctx, dr[2 * i].data_ptr(), dr[2 * i + 1].data_ptr(), cs[i].data_ptr(), N, gu.stream()))
+    for tile in (128, 256):
+        got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=dr + cs, seq_n=N, rope_dim=Dg, tile=tile, rope_pos=pos.to(gu.DEV))
+        assert gu.rel_err(got, ref) < tol, tile
+    # --- attention over packed rows; a sentinel row after each sequence region checks nothing spills
+    qkv = torch.randn(R, 3 * D, generator=g)
+    qkv[:, :D] *= 0.35
+    qkv = qkv.to(dtype)
+    out = torch.full((R + 8, D), 7.0, dtype=dtype, device=gu.DEV)
+    a = rt.vv_attn_args()
+    a.dtype = rt.VV_BF16 if dtype == torch.bfloat16 else rt.VV_F32
+    dq = qkv.to(gu.DEV)
+    a.qkv, a.ld_qkv, a.out, a.ld_out = dq.data_ptr(), 3 * D, out.data_ptr(), D
+    a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len, a.row_start = len(lens), N, heads, D, sl.data_ptr(), rs.data_ptr()
+    gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    f = qkv.float().reshape(R, 3, heads, 64)
+    for s_, L in enumerate(lens):
+        blk = f[starts[s_]: starts[s_] + L]
+        sc = torch.einsum("qhd,khd->hqk", blk[:, 0], blk[:, 1])
+        want = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), blk[:, 2]).reshape(L, D)
+        assert gu.rel_err(out[starts[s_]: starts[s_] + L], want) < tol, s_
+    assert bool((out[R:].float() == 7.0).all())
+    a.kv_len = None
+    assert eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()) != 0            # packed rows without lengths are refused
+    # --- conv position embedding over packed rows
+    x = torch.randn(R, D, generator=g).to(dtype)
+    w = (torch.randn(D, 64, KW, generator=g) / math.sqrt(64 * KW)).to(dtype)
+    bb = torch.randn(D, generator=g) * 0.1
+    wp = w.reshape(G, 64, 64, KW).permute(0, 3, 1, 2).contiguous() if dtype == torch.bfloat16 else w.reshape(G, 64, 64, KW).permute(0, 3, 2, 1).contiguous()
+    pout = torch.full((R + 8, D), 7.0, dtype=torch.float32, device=gu.DEV)
+    dx, dw, db = x.to(gu.DEV), wp.to(gu.DEV), bb.to(gu.DEV)
+    pa = rt.vv_posconv_args()
+    pa.dtype, pa.out_dtype = (rt.VV_BF16 if dtype == torch.bfloat16 else rt.VV_F32), rt.VV_F32
+    pa.in_, pa.ld_in, pa.W, pa.bias, pa.out, pa.ld_out = dx.data_ptr(), D, dw.data_ptr(), db.data_ptr(), pout.data_ptr(), D
+    pa.n_seq, pa.seq_n, pa.groups, pa.KW, pa.B, pa.seq_len, pa.row_start = len(lens), N, G, KW, len(lens), sl.data_ptr(), rs.data_ptr()
+    gu.check(eng, eng.lib.vv_posconv(eng.ctx, C.byref(pa), gu.stream()))
+    torch.cuda.synchronize()
+    for s_, L in enumerate(lens):
+        xs = x.float()[starts[s_]: starts[s_] + L]
+        want = F.mish(F.conv1d(xs.t().unsqueeze(0), w.float(), bb, padding=KW // 2, groups=G)).squeeze(0).t()
+        assert gu.rel_err(pout[starts[s_]: starts[s_] + L], want) < (5e-3 if dtype == torch.bfloat16 else TOL_F32), s_
+    assert bool((pout[R:] == 7.0).all())
+
+
 def test_gemm_rejects_bad_shapes(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]

@@ -151,8 +151,9 @@ class TTSEngine:
         if noise_blocks is None:      # the same seeded stream the session path draws from: one (N_i, n_mel) block per chunk, in item order
             noise_blocks = [torch.randn((n, spec.n_mel), generator=m.noise_gen, dtype=torch.float32) for n in seq_all]
         waves: List[Optional[np.ndarray]] = [None] * n_items
-        # length-bucketed ragged batches: every kernel but attention pays for B x N_max rows, so similar lengths ride together
-        for idx in plan_batches(seq_all, max(1, int(self.config.max_batch_chunks)), pad_frac=0.05, min_units=4):
+        # the device packs ragged rows, so padding is free for the acoustic stages; sorting by length still puts similar
+        # lengths into the same batch when a text has more chunks than max_batch_chunks (vocoder planes are padded)
+        for idx in plan_batches(seq_all, max(1, int(self.config.max_batch_chunks)), pad_frac=1.0):
             group = [inputs_list[i] for i in idx]
             B = len(group)
             lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)
@@ -192,7 +193,8 @@ class TTSEngine:
                     self._decode_graphs[key] = eng.capture_decode(*key)
                 pcm, pcm_len = self._decode_graphs[key](x, pre["ref_signal_len"], pre["seq_len"])
             else:
-                _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen)
+                _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen,
+                                                              gen_frames=[int(v) for v in (seq - ref_frames)])
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
             for i, j in enumerate(idx):
                 waves[j] = pcm[i, : pcm_len[i]].reshape(1, 1, -1)

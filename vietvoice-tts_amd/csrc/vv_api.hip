@@ -114,13 +114,14 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 // ---- GEMM helper over bound weights -------------------------------------------------------
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
-         const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1) {
+         const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
     g.A = A; g.lda = lda; g.W = c->W(wname); g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
+    g.rope_pos = rope_pos;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -363,12 +364,33 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     hipStream_t st = (hipStream_t)stream;
     const int D = g.dim, FF = D * g.ff_mult, M = g.n_mel, CD = M + g.text_dim, es = c->esz();
     const int KP = pad_to(M + CD, 64), MP = pad_to(M, 128);
-    const size_t R = (size_t)2 * B * N;
-    if (R > (size_t)1 << 30) return c->fail(-22, "batch too large");
+    if ((size_t)2 * B * N > (size_t)1 << 30) return c->fail(-22, "batch too large");
+    // Ragged rows are PACKED: sequence (branch, b) owns rows [row_start, +len_b) of every activation buffer, the conditional
+    // branch first, so GEMMs / norms / convs touch sum(len) rows instead of B x N_max.  The host needs the row count for the
+    // launch shapes: one 4*B-byte read-back per call.  x, cat and cat_drop keep their padded [B][N] layout (row_src maps).
+    std::vector<int> hlen(B);
+    HIPCHK(c, hipMemcpyAsync(hlen.data(), seq_len, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    size_t Rc = 0;
+    double sum_sq = 0;
+    for (int b = 0; b < B; ++b) {
+        if (hlen[b] < 1 || hlen[b] > N) return c->fail(-22, "vv_transformer_steps: seq_len[%d] = %d outside [1, %d]", b, hlen[b], N);
+        Rc += hlen[b]; sum_sq += (double)hlen[b] * hlen[b];
+    }
+    const size_t R = 2 * Rc;
+    std::vector<int> htab(2 * B + Rc + R);              // row_start[2B] | row_src[Rc] | row_pos[R]
+    {
+        int* rs = htab.data(); int* src = rs + 2 * B; int* pos = src + Rc;
+        size_t r = 0;
+        for (int b = 0; b < B; ++b) {
+            rs[b] = (int)r; rs[B + b] = (int)(Rc + r);
+            for (int t = 0; t < hlen[b]; ++t, ++r) { src[r] = b * N + t; pos[r] = t; pos[Rc + r] = t; }
+        }
+    }
     const int S = c->n_steps;
     Need nd;
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
-    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64);
+    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * htab.size());
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
@@ -382,6 +404,10 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     int* kv_len = carve<int>(c, 2 * B);
     float* csq = carve<float>(c, (size_t)N * 64);
     float* csk = carve<float>(c, (size_t)N * 64);
+    int* tab = carve<int>(c, htab.size());
+    HIPCHK(c, hipMemcpyAsync(tab, htab.data(), sizeof(int) * htab.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));                 // htab is a local: the copy must be done before it goes away
+    const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
     const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, csq, csk};
     KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
     KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
@@ -389,12 +415,12 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
         Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * R * (M + CD) / 2 + (double)es * R * KP, st);
-        KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, B * N, M, CD, 0, st, &m__));
+        KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, (int)Rc, M, CD, 0, row_src, st, &m__));
     }
     for (int s = step0; s < step0 + n_steps; ++s) {
         if (s != step0) {
-            Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * B * N * M + 2.0 * es * B * N * M, st);
-            KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, B * N, M, CD, 1, st, &m__));
+            Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * Rc * M + 2.0 * es * Rc * M, st);
+            KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, (int)Rc, M, CD, 1, row_src, st, &m__));
         }
         // input embedding: proj, then conv position embedding (two grouped convs + Mish) + residual
         if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_NONE_, xcat, KP, "input.proj.weight", KP, "input.proj.bias", h, D, (int)R, D, KP, st,
@@ -407,7 +433,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             a.W = c->W(wn); a.bias = c->Wf(bn);
             a.out = (j == 1) ? (void*)h2 : (void*)xres; a.ld_out = D;
             a.resid = (j == 2) ? h : nullptr; a.ld_resid = D;
-            a.n_seq = 2 * B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * B; a.seq_len = kv_len;
+            a.n_seq = 2 * B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * B; a.seq_len = kv_len; a.row_start = row_start;
             Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
             KCHK(c, vvk_posconv(&a, st, &m__));
         }
@@ -426,11 +452,11 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, row_pos)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
-                t.heads = g.heads; t.dim = D; t.kv_len = kv_len;
-                Prof p(c, VV_PROF_ATTN, 4.0 * 2 * B * g.heads * (double)N * N * 64, (double)es * R * 4 * D, st);
+                t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start;
+                Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D)) return r;
@@ -453,8 +479,8 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
         if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, h, D, "final.proj.weight", D, "final.proj.bias", pred, MP, (int)R, MP, D, st,
                          nullptr, M, nullptr, 0, 0, 2.0 * R * D * M)) return r;
         {
-            Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * B * N * M, st);
-            KCHK(c, vvk_cfg_euler(x, pred, MP, B * N, M, g.cfg_strength, c->dt_host[s], st, &m__));
+            Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * Rc * M, st);
+            KCHK(c, vvk_cfg_euler(x, pred, MP, (int)Rc, M, g.cfg_strength, c->dt_host[s], row_src, st, &m__));
         }
     }
     return 0;
@@ -613,7 +639,7 @@ int vv_normalize_clips(vv_ctx* c, const float* x, const int64_t* offsets, int n_
     SINGLE(c, vvk_normalize_clips(x, (const long long*)offsets, n_clips, (long long)max_len, stats, out, (hipStream_t)st, &m__));
 }
 int vv_cfg_euler(vv_ctx* c, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* st) {
-    SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, (hipStream_t)st, &m__));
+    SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, nullptr, (hipStream_t)st, &m__));
 }
 
 }  // extern "C"

@@ -23,7 +23,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // ------------------------------------------------------------------------------------ bf16
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
-                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr) {
+                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
+                                                           const int* __restrict__ row_start) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
     const int head = blockIdx.y, seq = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -31,13 +32,18 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     const int r32 = lane & 31, h = lane >> 5;
     int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
     kv_len = max(1, min(kv_len, seq_n));
+    // packed rows (row_start given): sequence `seq` owns rows [row_start[seq], +kv_len) only -- the rows after them are the
+    // next sequence's, so queries stop at kv_len and every row index is clamped inside the sequence.
+    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
+    const int q_lim = row_start ? kv_len : seq_n;
+    if ((int)blockIdx.x * 128 >= q_lim) return;
 
-    const bf16* Qp = qkv + (size_t)seq * seq_n * ld + head * 64;
+    const bf16* Qp = qkv + row0 * ld + head * 64;
     const bf16* Kp = Qp + D;
     const bf16* Vp = Qp + 2 * D;
 
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const int qrow = min(q0 + r32, seq_n - 1);
+    const int qrow = min(q0 + r32, q_lim - 1);
     bf16x8 qf[4];
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         for (int u = 0; u < 2; ++u) {
             const int q = wave * 2 + u;
             const int row = q * 8 + (lane >> 3);
-            const int key = min(kt * 64 + row, seq_n - 1);
+            const int key = min(kt * 64 + row, q_lim - 1);
             const int p = lane & 7;
             const int ck = p ^ ((row >> 1) & 7);              // swz128 (row reads, ds_read_b128)
             const int cv = p ^ (((row >> 1) & 1) << 2);       // V: conflict-free transposed reads
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + r32;
-    if (q < seq_n) {
-        bf16* op = out + ((size_t)seq * seq_n + q) * ldo + head * 64;
+    if (q < q_lim) {
+        bf16* op = out + (row0 + q) * ldo + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -179,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 
 // ------------------------------------------------------------------------------------ fp32
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
-                                                          int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr) {
+                                                          int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
+                                                          const int* __restrict__ row_start) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];   // per stage: K 16 KiB | V 16 KiB (256-B rows)
     const int head = blockIdx.y, seq = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -187,13 +194,16 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     const int r32 = lane & 31, h = lane >> 5;
     int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
     kv_len = max(1, min(kv_len, seq_n));
+    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;       // packed rows: see the bf16 kernel
+    const int q_lim = row_start ? kv_len : seq_n;
+    if ((int)blockIdx.x * 128 >= q_lim) return;
 
-    const float* Qp = qkv + (size_t)seq * seq_n * ld + head * 64;
+    const float* Qp = qkv + row0 * ld + head * 64;
     const float* Kp = Qp + D;
     const float* Vp = Qp + 2 * D;
 
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const int qrow = min(q0 + r32, seq_n - 1);
+    const int qrow = min(q0 + r32, q_lim - 1);
     f32x4 qf[8];   // lane half h takes d = 8kk + 4h + j: the same k pairing as the K fragment below
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const f32x4*)(Qp + (size_t)qrow * ld + kk * 8 + h * 4);
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
         for (int u = 0; u < 4; ++u) {
             const int q = wave * 4 + u;
             const int row = q * 4 + (lane >> 4);
-            const int key = min(kt * 64 + row, seq_n - 1);
+            const int key = min(kt * 64 + row, q_lim - 1);
             const int p = lane & 15;
             const int ck = p ^ (row & 15);
             glds16(Kp + (size_t)key * ld + ck * 4, base + q * 1024);
@@ -294,8 +304,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + r32;
-    if (q < seq_n) {
-        float* op = out + ((size_t)seq * seq_n + q) * ldo + head * 64;
+    if (q < q_lim) {
+        float* op = out + (row0 + q) * ldo + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -317,11 +327,12 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
         *err = "attention: qkv/out must be 16-byte aligned"; return -22;
     }
     if (a->ld_qkv < 3 * a->dim || a->ld_out < a->dim) { *err = "attention: leading dimensions too small"; return -22; }
+    if (a->row_start && !a->kv_len) { *err = "attention: packed rows need kv_len"; return -22; }
     dim3 grid((a->seq_n + 127) / 128, a->heads, a->n_seq);
     if (a->dtype == VV_BF16)
-        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len);
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start);
     else
-        attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len);
+        attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
     return 0;

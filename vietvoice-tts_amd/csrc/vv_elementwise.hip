@@ -74,13 +74,15 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_cat_kernel(const float* __restrict__ x, const float* __restrict__ cat,
                                                        const float* __restrict__ cat_drop, T* __restrict__ out, int ldo,
-                                                       int BN, int n_mel, int cond_dim, int only_x) {
+                                                       int BN, int n_mel, int cond_dim, int only_x,
+                                                       const int* __restrict__ row_src) {
     const int cols4 = (only_x ? n_mel : ldo) >> 2;
     const size_t total = (size_t)2 * BN * cols4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % cols4) * 4;
         const size_t row = i / cols4;
-        const size_t bt = row >= (size_t)BN ? row - BN : row;
+        size_t bt = row >= (size_t)BN ? row - BN : row;
+        if (row_src) bt = (size_t)row_src[bt];               // packed rows: bt indexes the padded [B][N] inputs
         float4 v;
         if (c < n_mel) v = *(const float4*)(x + bt * n_mel + c);
         else if (c < n_mel + cond_dim) v = *(const float4*)((row >= (size_t)BN ? cat_drop : cat) + bt * cond_dim + (c - n_mel));
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void pack_cat_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------- K9: x += dt * (pc + cfg (pc - pu))
 __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ x, const float* __restrict__ pred, int ldp,
-                                                        int BN, int n_mel, float cfg, float dt) {
+                                                        int BN, int n_mel, float cfg, float dt, const int* __restrict__ row_src) {
     const int c4 = n_mel >> 2;
     const size_t total = (size_t)BN * c4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -99,12 +101,13 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ x, c
         const size_t row = i / c4;
         const float4 pc = *(const float4*)(pred + row * ldp + c);
         const float4 pu = *(const float4*)(pred + (row + BN) * ldp + c);
-        float4 xv = *(float4*)(x + row * n_mel + c);
+        const size_t xr = row_src ? (size_t)row_src[row] : row;
+        float4 xv = *(float4*)(x + xr * n_mel + c);
         xv.x += dt * (pc.x + (pc.x - pu.x) * cfg);
         xv.y += dt * (pc.y + (pc.y - pu.y) * cfg);
         xv.z += dt * (pc.z + (pc.z - pu.z) * cfg);
         xv.w += dt * (pc.w + (pc.w - pu.w) * cfg);
-        *(float4*)(x + row * n_mel + c) = xv;
+        *(float4*)(x + xr * n_mel + c) = xv;
     }
 }
 
@@ -338,20 +341,21 @@ int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
 }
 
 int vvk_pack_cat(int dtype, const float* x, const float* cat, const float* cat_drop, void* out, int ldo, int BN, int n_mel,
-                 int cond_dim, int only_x, hipStream_t st, const char** err) {
+                 int cond_dim, int only_x, const int* row_src, hipStream_t st, const char** err) {
     if (n_mel % 4 || cond_dim % 4 || ldo % 4 || ldo < n_mel + cond_dim) { *err = "pack_cat: bad widths"; return -22; }
     const size_t total = (size_t)2 * BN * ((only_x ? n_mel : ldo) / 4);
     if (dtype == VV_BF16)
-        pack_cat_kernel<bf16><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (bf16*)out, ldo, BN, n_mel, cond_dim, only_x);
+        pack_cat_kernel<bf16><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (bf16*)out, ldo, BN, n_mel, cond_dim, only_x, row_src);
     else
-        pack_cat_kernel<float><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (float*)out, ldo, BN, n_mel, cond_dim, only_x);
+        pack_cat_kernel<float><<<grid_for(total), 256, 0, st>>>(x, cat, cat_drop, (float*)out, ldo, BN, n_mel, cond_dim, only_x, row_src);
     VVK_CHECK_LAUNCH();
     return 0;
 }
 
-int vvk_cfg_euler(float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, hipStream_t st, const char** err) {
+int vvk_cfg_euler(float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, const int* row_src, hipStream_t st,
+                  const char** err) {
     if (n_mel % 4 || ldp % 4) { *err = "cfg_euler: widths must be multiples of 4"; return -22; }
-    cfg_euler_kernel<<<grid_for((size_t)BN * n_mel / 4), 256, 0, st>>>(x, pred, ldp, BN, n_mel, cfg, dt);
+    cfg_euler_kernel<<<grid_for((size_t)BN * n_mel / 4), 256, 0, st>>>(x, pred, ldp, BN, n_mel, cfg, dt, row_src);
     VVK_CHECK_LAUNCH();
     return 0;
 }

@@ -41,6 +41,7 @@ struct EpiArgs {
     int act;
     int n_store;
     int seq_n;
+    const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
     int rope_dim;
     int dephase; // 100 MHz ticks per start-phase step for persistent blocks that own a spare tile slot (0 = off)
     int dbg;     // timing-only ablations (tools/gemm_bench.py): bit0 = no wait/barrier, bit1 = no loads in the loop
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         for (int mi = 0; mi < MI; ++mi) {
             const int m = bm + wr * MW + mi * 16 + r16;
             if (m >= M) continue;
-            const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
+            const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[m] : m % e.seq_n) : 0;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
                 epi_store<MODE, To>(e, C, ldc, m, pos, bn + wc * 64 + ni * 16 + cq * 4, acc[ni][mi][0], acc[ni][mi][1],
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         for (int mi = 0; mi < MI; ++mi) {
             const int m = bm + wr * MW + mi * 32 + r32;
             if (m >= M) continue;
-            const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
+            const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[m] : m % e.seq_n) : 0;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     const int mi = (ps & 1) * 2 + k;
                     const int lr = k * 16 + r16;
                     const int m = bm + g * 128 + ps * 32 + lr;
-                    const int pos = (MODE == MODE_QKV_ROPE) ? (min(m, M - 1) % e.seq_n) : 0;
+                    const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[min(m, M - 1)] : min(m, M - 1) % e.seq_n) : 0;
                     // RoPE: one 16-byte (cos, sin, cos, sin) load per 4 outputs from the compact table, all four issued first
                     float4 cs4[2][2];
                     bool do_rope = false;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                 for (int mi = 0; mi < 4; ++mi) {
                     const int m = bm + g * 128 + mh * 64 + mi * 16 + r16;
                     if (m >= M) continue;
-                    const int pos = (MODE == MODE_QKV_ROPE) ? (m % e.seq_n) : 0;
+                    const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[m] : m % e.seq_n) : 0;
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -660,7 +661,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
-    e.rope_dim = g->rope_dim;
+    e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos;
     { const char* d = getenv("VV_GEMM_DBG"); e.dbg = d ? atoi(d) : 0; }
     { const char* d = getenv("VV_GEMM_DEPHASE"); e.dephase = d ? atoi(d) : 0; }
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {

@@ -21,8 +21,9 @@ int vvk_mel(const int16_t* audio, int ld_audio, const int* audio_len, const floa
             const float* tw_sin, const float* fb, float* mel, int B, int F_max, int n_fft, int hop, int n_mel, hipStream_t st,
             const char** err);
 int vvk_pack_cat(int dtype, const float* x, const float* cat, const float* cat_drop, void* out, int ldo, int BN, int n_mel,
-                 int cond_dim, int only_x, hipStream_t st, const char** err);
-int vvk_cfg_euler(float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, hipStream_t st, const char** err);
+                 int cond_dim, int only_x, const int* row_src, hipStream_t st, const char** err);
+int vvk_cfg_euler(float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, const int* row_src, hipStream_t st,
+                  const char** err);
 int vvk_text_embed(const int* ids, int ld_ids, const int* text_len, const float* emb, const float* pos, float* out, int B, int N,
                    int Dt, int vocab_rows, hipStream_t st, const char** err);
 int vvk_dwconv(const float* in, float* out, const float* w, const float* bias, const int* seq_len, int B, int n_seq, int N, int C,

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(512, 2) void posconv_bf16_kernel(const bf16* __rest
                                                               const bf16* __restrict__ W /*[G][KW][64co][64ci]*/,
                                                               const float* __restrict__ bias, To* __restrict__ out, int ldo,
                                                               const bf16* __restrict__ resid, int ldr, int seq_n,
-                                                              const int* __restrict__ seq_len, int B, int KW) {
+                                                              const int* __restrict__ seq_len, int B, int KW,
+                                                              const int* __restrict__ row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][64 x 128 B] weight taps | (PC_TOK + KW - 1) rows x 128 B
     char* wbuf = smem;
     char* xwin = smem + 2 * 8192;
@@ -34,6 +35,10 @@ __global__ __launch_bounds__(512, 2) void posconv_bf16_kernel(const bf16* __rest
     const int t0 = blockIdx.x * PC_TOK;
     const int pad = KW / 2;
     const int len = seq_len ? min(seq_len[seq % B], seq_n) : seq_n;
+    // packed rows: the sequence owns rows [row_start[seq], +len) only; tokens beyond len are neither read nor written
+    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
+    const int t_lim = row_start ? len : seq_n;
+    if (t0 >= t_lim) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows = PC_TOK + KW - 1;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void posconv_bf16_kernel(const bf16* __rest
         const int r = i >> 3, c = i & 7;
         const int t = t0 + r - pad;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < len) v = *(const uint4*)(in + ((size_t)seq * seq_n + t) * ldi + g * 64 + c * 8);
+        if (t >= 0 && t < len) v = *(const uint4*)(in + (row0 + t) * ldi + g * 64 + c * 8);
         *(uint4*)(xwin + swz128(r, c)) = v;
     }
 
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(512, 2) void posconv_bf16_kernel(const bf16* __rest
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int t = t0 + wave * 32 + mi * 16 + r16;
-        if (t >= seq_n) continue;
-        const size_t row = (size_t)seq * seq_n + t;
+        if (t >= t_lim) continue;
+        const size_t row = row0 + t;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int co = g * 64 + ni * 16 + cq * 4;
@@ -108,19 +113,23 @@ __global__ __launch_bounds__(256) void posconv_f32_kernel(const float* __restric
                                                           const float* __restrict__ W /*[G][KW][64ci][64co]*/,
                                                           const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                           const float* __restrict__ resid, int ldr, int seq_n,
-                                                          const int* __restrict__ seq_len, int B, int KW) {
+                                                          const int* __restrict__ seq_len, int B, int KW,
+                                                          const int* __restrict__ row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // (PF_TOK + KW - 1) rows x 64 floats
     float* xs = (float*)smem;
     const int g = blockIdx.y, seq = blockIdx.z;
     const int t0 = blockIdx.x * PF_TOK;
     const int pad = KW / 2;
     const int len = seq_len ? min(seq_len[seq % B], seq_n) : seq_n;
+    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;       // packed rows: see the bf16 kernel
+    const int t_lim = row_start ? len : seq_n;
+    if (t0 >= t_lim) return;
     const int rows = PF_TOK + KW - 1;
     for (int i = threadIdx.x; i < rows * 16; i += 256) {
         const int r = i >> 4, c = i & 15;
         const int t = t0 + r - pad;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < len) v = *(const float4*)(in + ((size_t)seq * seq_n + t) * ldi + g * 64 + c * 4);
+        if (t >= 0 && t < len) v = *(const float4*)(in + (row0 + t) * ldi + g * 64 + c * 4);
         *(float4*)(xs + r * 64 + c * 4) = v;
     }
     __syncthreads();
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(256) void posconv_f32_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int t = t0 + tg * 16 + i;
-        if (t >= seq_n) break;
-        const size_t row = (size_t)seq * seq_n + t;
+        if (t >= t_lim) break;
+        const size_t row = row0 + t;
         float v = act_apply(acc[i] + b, VV_ACT_MISH);
         if (resid) v += resid[row * ldr + g * 64 + co];
         out[row * ldo + g * 64 + co] = v;
@@ -161,23 +170,24 @@ int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err) {
     if (a->groups <= 0 || a->n_seq <= 0 || a->seq_n <= 0) { *err = "posconv: empty shape"; return -22; }
     if (a->KW < 1 || a->KW > 63 || !(a->KW & 1)) { *err = "posconv: odd kernel width expected"; return -22; }
     if (a->ld_in < a->groups * 64 || a->ld_out < a->groups * 64) { *err = "posconv: 64 channels per group expected"; return -22; }
+    if (a->row_start && !a->seq_len) { *err = "posconv: packed rows need seq_len"; return -22; }
     if (a->dtype == VV_BF16) {
         if ((a->ld_in * 2) % 16 || (uintptr_t)a->in % 16 || (uintptr_t)a->W % 16) { *err = "posconv: alignment"; return -22; }
         dim3 grid((a->seq_n + PC_TOK - 1) / PC_TOK, a->groups, a->n_seq);
         const size_t lds = (size_t)(PC_TOK + a->KW - 1) * 128 + 2 * 8192;
         if (a->out_dtype == VV_BF16)
             posconv_bf16_kernel<bf16><<<grid, 512, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (bf16*)a->out,
-                                                              a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+                                                              a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW, a->row_start);
         else
             posconv_bf16_kernel<float><<<grid, 512, lds, st>>>((const bf16*)a->in, a->ld_in, (const bf16*)a->W, a->bias, (float*)a->out,
-                                                               a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+                                                               a->ld_out, (const bf16*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW, a->row_start);
     } else {
         if (a->out_dtype != VV_F32) { *err = "posconv: f32 path writes f32"; return -22; }
         if ((a->ld_in * 4) % 16 || (uintptr_t)a->in % 16) { *err = "posconv: alignment"; return -22; }
         dim3 grid((a->seq_n + PF_TOK - 1) / PF_TOK, a->groups, a->n_seq);
         const size_t lds = (size_t)(PF_TOK + a->KW - 1) * 256;
         posconv_f32_kernel<<<grid, 256, lds, st>>>((const float*)a->in, a->ld_in, (const float*)a->W, a->bias, (float*)a->out, a->ld_out,
-                                                   (const float*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW);
+                                                   (const float*)a->resid, a->ld_resid, a->seq_n, a->seq_len, a->B, a->KW, a->row_start);
     }
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }

@@ -50,12 +50,13 @@ class vv_gemm_args(C.Structure):
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("cos_q", C.c_void_p), ("sin_q", C.c_void_p),
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
-                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32)]
+                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p)]
 
 
 class vv_attn_args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("qkv", C.c_void_p), ("ld_qkv", C.c_int32), ("out", C.c_void_p), ("ld_out", C.c_int32),
-                ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p)]
+                ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p),
+                ("row_start", C.c_void_p)]
 
 
 class vv_ln_args(C.Structure):
@@ -69,7 +70,7 @@ class vv_posconv_args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("out_dtype", C.c_int32), ("in_", C.c_void_p), ("ld_in", C.c_int32), ("W", C.c_void_p),
                 ("bias", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int32), ("resid", C.c_void_p), ("ld_resid", C.c_int32),
                 ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("groups", C.c_int32), ("KW", C.c_int32), ("B", C.c_int32),
-                ("seq_len", C.c_void_p)]
+                ("seq_len", C.c_void_p), ("row_start", C.c_void_p)]
 
 
 class vv_conv_args(C.Structure):
@@ -286,13 +287,40 @@ class HipSynth:
                                            t_gen_max, pcm.data_ptr(), pcm.shape[1], pcm_len.data_ptr(), _ptr(wave), self._stream()))
         return (pcm, pcm_len, wave) if want_wave else (pcm, pcm_len)
 
+    def decode_bucketed(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], gen_frames, pad_frac: float = 0.10, min_units: int = 4):
+        """The vocoder works on padded [B][C][T_max] planes (the acoustic stages pack ragged rows, the conv stack does not),
+        so a ragged batch is decoded in length buckets.  gen_frames: host list of generated frames per item."""
+        from .sharding import plan_batches
+        B = x.shape[0]
+        hop = self.spec.hop_length
+        t_max = int(max(gen_frames))
+        groups = plan_batches([int(f) for f in gen_frames], B, pad_frac=pad_frac, min_units=min_units)
+        if len(groups) == 1:
+            return self.decode(x, pre, t_max)
+        pcm = torch.zeros((B, t_max * hop), dtype=torch.int16, device=self.device)
+        pcm_len = torch.empty((B,), dtype=torch.int32, device=self.device)
+        for grp in groups:
+            idx = torch.tensor(grp, dtype=torch.int64, device=self.device)
+            sub = {"ref_signal_len": pre["ref_signal_len"].index_select(0, idx).contiguous(), "seq_len": pre["seq_len"].index_select(0, idx).contiguous()}
+            t_g = int(max(gen_frames[i] for i in grp))
+            p, n = self.decode(x.index_select(0, idx).contiguous(), sub, t_g)
+            pcm[idx, : t_g * hop] = p
+            pcm_len[idx] = n
+        return pcm, pcm_len
+
     def synthesize_batch(self, audio, audio_len, text_ids, text_len, seq_len, N: int, noise: torch.Tensor, t_gen_max: int,
-                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None):
-        """Whole hot path for a batch, state resident in HBM: preprocess -> ODE steps -> vocoder."""
+                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None, gen_frames=None):
+        """Whole hot path for a batch, state resident in HBM: preprocess -> ODE steps -> vocoder.
+        gen_frames (host list, optional): per-item generated frames; lets the vocoder run in length buckets on ragged batches."""
         pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len)
         x = noise.clone()
         self.transformer_steps(x, pre, 0, self.n_steps if n_steps is None else n_steps)
-        pcm, pcm_len = self.decode(x, pre, t_gen_max)
+        if gen_frames is not None and len(gen_frames) == x.shape[0]:
+            pcm, pcm_len = self.decode_bucketed(x, pre, gen_frames)
+            if pcm.shape[1] < t_gen_max * self.spec.hop_length:
+                pcm = torch.nn.functional.pad(pcm, (0, t_gen_max * self.spec.hop_length - pcm.shape[1]))
+        else:
+            pcm, pcm_len = self.decode(x, pre, t_gen_max)
         return x, pcm, pcm_len, pre
 
     # ------------------------------------------------------------------ hipGraph-captured vocoder step (config 5)
