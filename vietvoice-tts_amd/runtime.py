@@ -18,7 +18,7 @@ from . import pack
 from .model_spec import ModelSpec, time_grid
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvvtts_hip.so")
+LIB_PATH = os.environ.get("VVTTS_LIB") or os.path.join(_HERE, "libvvtts_hip.so")   # VVTTS_LIB: A/B builds in tools/
 
 VV_F32, VV_BF16 = 0, 1
 PROF_CLASSES = ["gemm", "attention", "norm", "posconv", "elementwise", "voc_conv", "voc_post", "mel", "text"]
