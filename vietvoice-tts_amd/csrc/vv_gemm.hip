@@ -43,7 +43,6 @@ struct EpiArgs {
     int seq_n;
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
     int rope_dim;
-    int dephase; // 100 MHz ticks per start-phase step for persistent blocks that own a spare tile slot (0 = off)
     int dbg;     // timing-only ablations (tools/gemm_bench.py): bit0 = no wait/barrier, bit1 = no loads in the loop
 };
 
@@ -314,15 +313,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     const int n_entries = (m_tiles > x ? (m_tiles - x + 7) / 8 : 0) * n_tiles;
     if (jb >= n_entries) return;
     const int n_my = (n_entries - jb + bpx - 1) / bpx;
-    if (e.dephase > 0) {
-        // Blocks that run one tile fewer than the longest block start late by 1..3 quarter-tile steps: the chip no longer
-        // stores all its tiles in the same few microseconds (the epilogue burst runs at HBM write peak while MFMA idles).
-        const int n_cap = (((m_tiles + 7) / 8) * n_tiles + bpx - 1) / bpx;
-        if (n_my < n_cap) {
-            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((jb % 3) + 1) * (unsigned)e.dephase;
-            while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     auto tile_bm = [&](int i) { return (((jb + i * bpx) / n_tiles) * 8 + x) * 256; };
     auto tile_bn = [&](int i) { return ((jb + i * bpx) % n_tiles) * 256; };
 
@@ -682,7 +672,6 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos;
     { const char* d = getenv("VV_GEMM_DBG"); e.dbg = d ? atoi(d) : 0; }
-    { const char* d = getenv("VV_GEMM_DEPHASE"); e.dephase = d ? atoi(d) : 0; }
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {
         *err = "gemm: rope epilogue needs the four tables and rope_dim % 64 == 0"; return -22;
     }
