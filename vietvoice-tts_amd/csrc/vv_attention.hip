@@ -18,6 +18,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_T = 8.0f / LOG2E;      // bf16 kernel: tolerate 2^8 of head-room before rescaling O and l
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -120,8 +121,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        // rescale only when some row's running max grew (wave-uniform branch); alpha == 1 otherwise, so skipping is exact
-        if (__any(m_new > m_run)) {
+        // Deferred rescale: the running max is only moved when some row's max grew by more than RESCALE_T (wave-uniform
+        // branch).  Softmax is invariant to the subtracted constant; a stale max only means p <= 2^(RESCALE_T log2e) = 256
+        // instead of <= 1, far inside f32 / bf16 range, and O, l and p of a tile always see the same m_run.
+        if (__any(m_new > m_run + RESCALE_T)) {
             const float alpha = fast_exp2((m_run - m_new) * LOG2E);
             l_run *= alpha;
 #pragma unroll
