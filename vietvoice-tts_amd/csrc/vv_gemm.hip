@@ -671,7 +671,10 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos;
-    { const char* d = getenv("VV_GEMM_DBG"); e.dbg = d ? atoi(d) : 0; }
+    {   // timing-only ablation bits for tools/gemm_bench.py; read once per process, 0 in production
+        static const int dbg_env = [] { const char* d = getenv("VV_GEMM_DBG"); return d ? atoi(d) : 0; }();
+        e.dbg = dbg_env;
+    }
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {
         *err = "gemm: rope epilogue needs the four tables and rope_dim % 64 == 0"; return -22;
     }
