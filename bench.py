@@ -263,8 +263,14 @@ def main():
     gm = prof["gemm"]
     peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+    traffic, traffic_src = None, None                 # HBM-side bytes per launch from the committed PMC passes (bench.py cannot run rocprofv3 itself)
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "gemm_pmc_traffic.json")
+    if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
+        with open(tf) as fh:
+            tj = json.load(fh)
+        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01/gemm_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
     roofline = {"bound": "mfma", "kernel": "gemm_kernel (K6, %s MFMA)" % a.dtype, "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4)}
     def _rf(name, bound, peak):
         v = prof[name]
