@@ -215,6 +215,44 @@ def test_packed_rows_rope_attention_posconv(hip_tiny, dtype, tiny_setup):
     assert bool((pout[R:] == 7.0).all())
 
 
+@pytest.mark.parametrize("N,K,act", [(1024, 1024, 0), (2048, 512, 1), (768, 256, 1)])
+def test_gemm_persistent_blocks_walk_several_tiles(hip_tiny, N, K, act):
+    """More tiles than CUs: every persistent workgroup runs 2+ tiles back to back, which is the only path where the first
+    K-tile of a tile overlaps the previous tile's 16 epilogue stores (vmcnt(24) instead of vmcnt(8) in the store mode) and
+    where the staging schedule rolls over from one tile into the next.  Checked against an fp32 matmul of the same bf16
+    operands on the device; M is ragged so the last m-tile is partial (no relaxed wait after a partial store)."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    M = 256 * 90 + 77
+    g = torch.Generator().manual_seed(N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gu.DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(gu.DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(gu.DEV)
+    gate = torch.randn(N, generator=g).to(gu.DEV)
+    y = A.float() @ W.float().t() + b
+    want = F.gelu(y, approximate="tanh") if act else y
+    for rep in range(3):                       # timing-dependent hazards would not show on every launch
+        got = gu.gemm(eng, A, W, bias=b, act=act, tile=256)
+        assert gu.rel_err(got, want) < TOL_BF16, rep
+    dl = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, tile=256)
+    assert gu.rel_err(dl, gate * y) < TOL_BF16
+    if N == 768:                               # rope epilogue over several tiles per workgroup (positions = row % seq_n)
+        from oracle.vv_oracle import Oracle
+        seq_n, Dq = 1600, 256
+        pos = torch.arange(seq_n, dtype=torch.float32)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+        ang = torch.repeat_interleave(pos[:, None] * inv[None, :], 2, dim=1)          # pair-duplicated tables [seq_n][64]
+        ropes = [ang.cos() * 0.125, ang.sin() * 0.125, ang.cos(), ang.sin()]
+        q, k, v = y.cpu().split(Dq, dim=-1)
+        idx = torch.arange(M) % seq_n
+        tabs = [t[idx] for t in ropes]
+        ref = torch.cat([Oracle.rope_apply(q.reshape(M, Dq // 64, 64), tabs[0], tabs[1]).reshape(M, Dq),
+                         Oracle.rope_apply(k.reshape(M, Dq // 64, 64), tabs[2], tabs[3]).reshape(M, Dq), v], dim=-1)
+        dr = [t.contiguous().to(gu.DEV) for t in ropes]
+        got = gu.gemm(eng, A, W, bias=b, mode=1, ropes=dr, seq_n=seq_n, rope_dim=Dq, tile=256)
+        assert gu.rel_err(got, ref) < TOL_BF16
+
+
 def test_gemm_rejects_bad_shapes(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]
