@@ -31,13 +31,16 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
                                                            float pre_slope, float out_scale, int accumulate,
                                                            const int* __restrict__ len_in) {
     constexpr int VR = RT * 32;
-    // halo: conv reads time + kw*dil - left; transposed reads q and q-1
+    // halo: conv reads time + kw*dil - left; transposed reads q and q-1.  The staged window starts at the 16-byte aligned
+    // time q0 - L4 (L4 = left rounded up to 4), so whole float4s are loaded and the reads shift by L4 - left.
     const int left = TRANSPOSED ? 1 : dil * (KW - 1) / 2;
     const int span = TRANSPOSED ? 1 : dil * (KW - 1);
-    const int xw = VT + span;                         // staged window width per channel
+    const int L4 = (left + 3) & ~3;
+    const int shift = L4 - left;
+    const int xw4 = (VT + span + shift + 3) >> 2;     // float4s per channel
+    const int xw_pad = xw4 * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;                         // [VCI][xw_pad]
-    const int xw_pad = (xw + 3) & ~3;
     float* ws = xs + VCI * xw_pad;                    // [VCI][KW][VR]
 
     const int b = blockIdx.z;
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
     const int r32 = lane & 31, h = lane >> 5;
     const int lin = len_in ? min(len_in[b], T_in) : T_in;
     const float* inb = in + (size_t)b * Cin * T_in;
+    const bool vec_ok = (T_in & 3) == 0 && ((uintptr_t)in & 15) == 0;
 
     f32x16 acc[RT][2];
 #pragma unroll
@@ -61,13 +65,27 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
     // was measured slower here because its staging maps halve the occupancy.
     for (int c0 = 0; c0 < Cin; c0 += VCI) {
         __syncthreads();
-        // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 + i - left])
-        for (int i = threadIdx.x; i < VCI * xw; i += 256) {
-            const int c = i / xw, k = i - c * xw;
-            const int pos = q0 + k - left;
-            float v = 0.f;
-            if (c0 + c < Cin && pos >= 0 && pos < lin) v = lrelu(inb[(size_t)(c0 + c) * T_in + pos], pre_slope);
-            xs[c * xw_pad + k] = v;
+        // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 - L4 + i]), zero outside [0, lin); wave w takes
+        // channels w, w+4, ...; aligned float4 loads wherever the four samples are inside the row
+        for (int c = wave; c < VCI; c += 4) {
+            const bool live = c0 + c < Cin;
+            const float* row = inb + (size_t)(c0 + c) * T_in;
+            for (int i4 = lane; i4 < xw4; i4 += 64) {
+                const int pos = q0 - L4 + i4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) {
+                    if (vec_ok && pos >= 0 && pos + 3 < lin) {
+                        v = *(const float4*)(row + pos);
+                    } else {
+                        if (pos >= 0 && pos < lin) v.x = row[pos];
+                        if (pos + 1 >= 0 && pos + 1 < lin) v.y = row[pos + 1];
+                        if (pos + 2 >= 0 && pos + 2 < lin) v.z = row[pos + 2];
+                        if (pos + 3 >= 0 && pos + 3 < lin) v.w = row[pos + 3];
+                    }
+                    v.x = lrelu(v.x, pre_slope); v.y = lrelu(v.y, pre_slope); v.z = lrelu(v.z, pre_slope); v.w = lrelu(v.w, pre_slope);
+                }
+                *(float4*)(xs + c * xw_pad + i4 * 4) = v;
+            }
         }
         // ---- stage the weight slab: ws[c][kw][r] = Wt[c0+c][kw][r0+r]   (padded, no masks)
         for (int i = threadIdx.x; i < VCI * KW * (VR / 4); i += 256) {
@@ -80,7 +98,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
             const int c = 2 * j + h;                   // lane half h takes channel 2j + h
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
-                const int off = TRANSPOSED ? (left - kw) : kw * dil;          // window index = local time + off
+                const int off = (TRANSPOSED ? (left - kw) : kw * dil) + shift;          // window index = local time + off
                 float a[RT], x[2];
 #pragma unroll
                 for (int i = 0; i < RT; ++i) a[i] = ws[(c * KW + kw) * VR + i * 32 + r32];
@@ -228,7 +246,8 @@ template <int KW, bool TR, int VCI, int RT>
 int launch_conv_t(const vv_conv_args* a, hipStream_t st) {
     constexpr int VR = RT * 32;
     const int span = TR ? 1 : a->dil * (KW - 1);
-    const int xw_pad = (VT + span + 3) & ~3;
+    const int left = TR ? 1 : a->dil * (KW - 1) / 2;
+    const int xw_pad = ((VT + span + (((left + 3) & ~3) - left) + 3) >> 2) * 4;
     const size_t lds = (size_t)(VCI * xw_pad + VCI * KW * VR) * sizeof(float);
     const int q_total = TR ? a->T_in + 1 : a->T_out;
     dim3 grid((q_total + VT - 1) / VT, (a->rows_total + VR - 1) / VR, a->B);
