@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Latency hiding is by occupancy (3-4 workgroups per CU at ~100 VGPRs): a register-prefetch pipeline
-    // was measured slower here because its staging maps halve the occupancy.
+    // Latency hiding is by occupancy: small channel chunks (VCI 4 for k = 7 / 11, 8 for k = 3, 16 for the transposed form,
+    // measured best of 2..32) keep the LDS footprint at 8-16 KiB so up to 8 workgroups share a CU; a register-prefetch
+    // pipeline was measured slower because its staging maps halve the occupancy.
     for (int c0 = 0; c0 < Cin; c0 += VCI) {
         __syncthreads();
         // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 - L4 + i]), zero outside [0, lin); wave w takes
@@ -275,9 +276,9 @@ int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
     } else {
         if (a->rows_total != a->Cout || a->T_out != a->T_in || a->dil < 1 || a->dil > 5) { *err = "conv: bad conv shape (dilation 1..5)"; return -22; }
         switch (a->KW) {
-            case 3: launch_conv<3, false, 16>(a, st); break;
-            case 7: launch_conv<7, false, 8>(a, st); break;
-            case 11: launch_conv<11, false, 8>(a, st); break;
+            case 3: launch_conv<3, false, 8>(a, st); break;
+            case 7: launch_conv<7, false, 4>(a, st); break;
+            case 11: launch_conv<11, false, 4>(a, st); break;
             default: *err = "conv: kernel width must be 3, 7 or 11"; return -22;
         }
     }
