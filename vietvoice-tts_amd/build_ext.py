@@ -15,6 +15,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvvtts_hip.so")
 SOURCES = ["vv_gemm", "vv_attention", "vv_elementwise", "vv_posconv", "vv_vocoder", "vv_mel", "vv_ingest", "vv_api"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+EXTRA_FLAGS = {}      # per-file extras (none needed at present)
 
 
 def _hipcc() -> str:
@@ -41,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src, obj = os.path.join(CSRC, name + ".hip"), os.path.join(OBJ, name + ".o")
         if not force and _newer(obj, [src] + headers):
             return obj, False
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(name, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -455,7 +455,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, row_pos)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
-                t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start;
+                t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
                 Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }

@@ -21,11 +21,22 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float RESCALE_T = 8.0f / LOG2E;      // bf16 kernel: tolerate 2^8 of head-room before rescaling O and l
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// max / sum across the two 32-lane halves with the gfx950 half swap (one v_permlane32_swap instead of a ds_bpermute round trip)
+__device__ __forceinline__ float half_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));   // no canonicalising pre-max
+    return d;
+}
+__device__ __forceinline__ float half_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // ------------------------------------------------------------------------------------ bf16
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                           const int* __restrict__ row_start) {
+                                                           const int* __restrict__ row_start, int total_rows) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
     const int head = blockIdx.y, seq = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -41,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 
     const bf16* Qp = qkv + row0 * ld + head * 64;
     const bf16* Kp = Qp + D;
-    const bf16* Vp = Qp + 2 * D;
+    // bytes from Kp to the end of the qkv buffer (host-checked < 2 GiB): the bound of the K/V buffer resource
+    const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
 
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int qrow = min(q0 + r32, q_lim - 1);
@@ -49,19 +61,30 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
 
-    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each
+    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  buffer_load ... lds
+    // with a per-lane byte offset that advances by one add per piece and tile (the advance stays in the VGPR offset: the
+    // SGPR offset of a buffer instruction is not range-checked).  Rows past the end of the buffer (last tile of the last
+    // sequence) read as zero instead of needing a clamp; rows past the sequence but inside the buffer are the next
+    // sequence's (finite data) and are masked like any key >= kv_len.
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)kv_bytes, 0x00020000);
+    unsigned voff_k[2], voff_v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = (wave * 2 + u) * 8 + (lane >> 3);
+        const int p = lane & 7;
+        const int ck = p ^ ((row >> 1) & 7);              // swz128 (row reads, ds_read_b128)
+        const int cv = p ^ (((row >> 1) & 1) << 2);       // V: conflict-free transposed reads
+        voff_k[u] = (unsigned)row * (unsigned)ld * 2u + ck * 16;
+        voff_v[u] = (unsigned)row * (unsigned)ld * 2u + (unsigned)D * 2u + cv * 16;      // V = K + D columns
+    }
+    const int tile_bytes = 64 * ld * 2;
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * 16384;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = wave * 2 + u;
-            const int row = q * 8 + (lane >> 3);
-            const int key = min(kt * 64 + row, q_lim - 1);
-            const int p = lane & 7;
-            const int ck = p ^ ((row >> 1) & 7);              // swz128 (row reads, ds_read_b128)
-            const int cv = p ^ (((row >> 1) & 1) << 2);       // V: conflict-free transposed reads
-            glds16(Kp + (size_t)key * ld + ck * 8, base + q * 1024);
-            glds16(Vp + (size_t)key * ld + cv * 8, base + 8192 + q * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + q * 1024), 16, (int)(voff_k[u] + kt * tile_bytes), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + 8192 + q * 1024), 16, (int)(voff_v[u] + kt * tile_bytes), 0, 0, 0);
         }
     };
 
@@ -119,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
         const float m_new = fmaxf(m_run, mx);
         // Deferred rescale: the running max is only moved when some row's max grew by more than RESCALE_T (wave-uniform
         // branch).  Softmax is invariant to the subtracted constant; a stale max only means p <= 2^(RESCALE_T log2e) = 256
@@ -133,23 +156,19 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m_run = m_new;
         }
-        // p = 2^(s*log2e - m*log2e), two lanes of math per instruction (v_pk_fma_f32 / v_pk_add_f32)
-        const f32x2 msc2 = {-m_run * LOG2E, -m_run * LOG2E};
-        const f32x2 l2e2 = {LOG2E, LOG2E};
-        f32x2 ps2 = {0.f, 0.f};
+        // p = 2^(s*log2e - m*log2e): single f32 instructions on purpose -- packed f32 VALU (v_pk_fma/add_f32) issues slowly
+        // beside MFMAs on gfx950 (measured 1011 -> 989 us on the benchmark shape when unpacked)
+        const float msc = -m_run * LOG2E;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};          // four independent sum chains
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 a = {s[kb][r], s[kb][r + 1]};
-                a = a * l2e2 + msc2;
-                a[0] = fast_exp2(a[0]);
-                a[1] = fast_exp2(a[1]);
-                ps2 += a;
-                s[kb][r] = a[0];
-                s[kb][r + 1] = a[1];
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(fmaf(s[kb][r], LOG2E, msc));
+                ps[r & 3] += pv;
+                s[kb][r] = pv;
             }
-        l_run += ps2[0] + ps2[1];
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 
         // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
 #pragma unroll
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 }
             }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = half_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int q = q0 + r32;
     if (q < q_lim) {
@@ -331,9 +350,12 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     }
     if (a->ld_qkv < 3 * a->dim || a->ld_out < a->dim) { *err = "attention: leading dimensions too small"; return -22; }
     if (a->row_start && !a->kv_len) { *err = "attention: packed rows need kv_len"; return -22; }
+    const int total_rows = a->total_rows > 0 ? a->total_rows : a->n_seq * a->seq_n;
+    if (a->dtype == VV_BF16 && (size_t)total_rows * a->ld_qkv * 2 >= ((size_t)1 << 31)) { *err = "attention: qkv buffer must stay below 2 GiB"; return -22; }
+    if (a->row_start == nullptr && total_rows < a->n_seq * a->seq_n) { *err = "attention: total_rows smaller than n_seq * seq_n"; return -22; }
     dim3 grid((a->seq_n + 127) / 128, a->heads, a->n_seq);
     if (a->dtype == VV_BF16)
-        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start);
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows);
     else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start);
     hipError_t he = hipGetLastError();
