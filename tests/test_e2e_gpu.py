@@ -173,3 +173,32 @@ def test_bucketed_decode_equals_one_batch(hip_tiny, tiny_setup):
     for b in range(len(gf)):
         n = int(len_1[b])
         assert n == gf[b] * spec.hop_length and torch.equal(pcm_1[b, :n], pcm_b[b, :n])
+
+
+def test_bf16_pipeline_through_the_persistent_gemm(hip_tiny):
+    """'small' preset (D = 256, 3 blocks) on a ragged batch whose packed row count passes 4096, so every block GEMM takes
+    the persistent 256x256 ping-pong kernel (QKV rope with the per-row position table, gate-store, GELU store with the
+    relaxed first-K-tile wait), attention and pos-conv run on packed rows of four different lengths, and the two-delta /
+    keep_x LayerNorm protocol carries the residual stream -- against the fp32 CPU oracle, bf16 tolerance."""
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    from oracle.vv_oracle import Oracle
+    spec = ModelSpec.small()
+    w = make_synthetic_weights(spec, seed=4242)
+    orc = Oracle(spec, w, nfe_step=4)
+    eng = HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4)
+    la = [256 * 60, 256 * 45 + 17, 256 * 70, 256 * 52]
+    gf = [560, 520, 470, 540]
+    batch = make_batch(spec, la, [40, 33, 47, 38], gf, seed=77)
+    assert 2 * int(batch["seq_len"].sum()) >= 4096
+    n_steps = 3
+    ref = run_oracle(orc, batch, n_steps)
+    pre, x, pcm, pcm_len, wave = run_hip(eng, batch, n_steps)
+    for b, r in enumerate(ref):
+        sl = int(batch["seq_len"][b])
+        d = x[b, :sl] - r["x"]
+        rmse = float(d.pow(2).mean().sqrt() / r["x"].pow(2).mean().sqrt())
+        assert rmse < 2e-2, (b, rmse)
+        n = r["wave"].numel()
+        assert int(pcm_len[b]) == n
+    eng.close()
