@@ -18,7 +18,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_T = 8.0f / LOG2E;      // bf16 kernel: tolerate 2^8 of head-room before rescaling O and l
+constexpr float RESCALE_T = 8.0f;              // bf16 kernel, log2 domain: tolerate 2^8 of head-room before re-referencing
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // max / sum across the two 32-lane halves with the gfx950 half swap (one v_permlane32_swap instead of a ds_bpermute round trip)
@@ -27,6 +27,18 @@ __device__ __forceinline__ float half_max(float v) {
     float d;
     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));   // no canonicalising pre-max
     return d;
+}
+__device__ __forceinline__ float bf16_round(float v) {           // round to nearest even onto the bf16 grid, result as f32
+    const unsigned u = __float_as_uint(v);
+    return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+}
+// fragment of the extra contraction step: value at k = 0 of lane half 0, zero elsewhere (v must be bf16-representable)
+__device__ __forceinline__ bf16x8 make_q_ext(float v, int h) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+    f[0] = (bf16)(h == 0 ? v : 0.f);
+    return f;
 }
 __device__ __forceinline__ float half_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -59,7 +71,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     const int qrow = min(q0 + r32, q_lim - 1);
     bf16x8 qf[4];
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
+    for (int ds = 0; ds < 4; ++ds) {
+        qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
+    }
 
     // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  buffer_load ... lds
     // with a per-lane byte offset that advances by one add per piece and tile (the advance stays in the VGPR offset: the
@@ -93,7 +109,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_eff = 0.f, l_run = 0.f;              // m_eff: row reference in the log2 domain, bf16-representable
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    const bf16x8 k_one = make_q_ext(1.0f, h);    // K side of the 65th contraction element: 1.0 at k = 0 of lane half 0
+    bf16x8 q_ext = make_q_ext(0.f, h);           // Q side: -m_eff
 
     // transposed-read lane constants: 16-lane group g reads a 4-key x 16-d block.  Per d-tile the byte offset of this
     // lane's 8-byte piece inside a 16-key slab is a constant; (key block, k-step, +8 rows) are immediates.
@@ -114,12 +135,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         const char* sK = smem + (kt & 1) * 16384;
         const char* sV = sK + 8192;
 
-        // ---- S^T = K Q^T : s[kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32
+        // ---- S'^T = K Q^T - m : scores arrive in the log2 domain (Q fragments carry log2e) and ALREADY SHIFTED by the
+        // row reference m_eff: the shift rides as a 65th contraction element (K side 1.0, Q side -m_eff, one extra MFMA
+        // per key block) instead of 32 VALU fmas per tile -- the loop is VALU-bound (profiles/r01/attention_notes.md).
+        // s[kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) {
                 const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
@@ -143,28 +166,36 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
-        const float m_new = fmaxf(m_run, mx);
-        // Deferred rescale: the running max is only moved when some row's max grew by more than RESCALE_T (wave-uniform
-        // branch).  Softmax is invariant to the subtracted constant; a stale max only means p <= 2^(RESCALE_T log2e) = 256
-        // instead of <= 1, far inside f32 / bf16 range, and O, l and p of a tile always see the same m_run.
-        if (__any(m_new > m_run + RESCALE_T)) {
-            const float alpha = fast_exp2((m_run - m_new) * LOG2E);
-            l_run *= alpha;
+        // Deferred re-reference (wave-uniform branch): m_eff moves on the first tile and then only when some row's shifted
+        // max passes RESCALE_T (2^8 of head-room).  Softmax is invariant to the subtracted constant, so a stale m_eff only
+        // means p <= 256 instead of <= 1.  m_eff is kept bf16-representable so that the MFMA subtracts it exactly and O, l
+        // and p always see the same reference.
+        if (kt == 0 || __any(mx > RESCALE_T)) {
+            const float m_new = bf16_round(kt == 0 ? mx : m_eff + fmaxf(mx, 0.f));
+            const float d = m_new - m_eff;                     // exact: both are bf16 values
+            if (kt != 0) {                                     // O and l are zero on the first tile
+                const float alpha = fast_exp2(-d);
+                l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            m_run = m_new;
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= d;    // this tile was shifted by the old reference
+            m_eff = m_new;
+            q_ext = make_q_ext(-m_new, h);
         }
-        // p = 2^(s*log2e - m*log2e): single f32 instructions on purpose -- packed f32 VALU (v_pk_fma/add_f32) issues slowly
-        // beside MFMAs on gfx950 (measured 1011 -> 989 us on the benchmark shape when unpacked)
-        const float msc = -m_run * LOG2E;
+        // p = 2^s' : single f32 instructions on purpose -- packed f32 VALU (v_pk_fma/add_f32) issues slowly beside MFMAs on
+        // gfx950 (measured 1011 -> 989 us on the benchmark shape when unpacked)
         float ps[4] = {0.f, 0.f, 0.f, 0.f};          // four independent sum chains
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(fmaf(s[kb][r], LOG2E, msc));
+                const float pv = fast_exp2(s[kb][r]);
                 ps[r & 3] += pv;
                 s[kb][r] = pv;
             }
