@@ -30,7 +30,15 @@ def _worker(rank, world, port, q):
     mine = sharding.shard_units([sharding.unit_cost(f) for f in frames], world)[rank]
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
-    q.put((rank, ok_bytes, int(flat.sum()), gathered, len(table)))
+    # C2: ragged PCM of each rank's units gathered in global unit order
+    g = torch.Generator().manual_seed(100 + rank)
+    lens = [40 + 7 * u for u in mine]
+    pcm = torch.zeros(len(mine), max(lens), dtype=torch.int16)
+    for j, u in enumerate(mine):
+        pcm[j, : lens[j]] = torch.full((lens[j],), u + 1, dtype=torch.int16)
+    allpcm = sharding.gather_pcm(pcm, torch.tensor(lens, dtype=torch.int32), mine, len(frames))
+    ok_pcm = all(t.numel() == 40 + 7 * u and bool((t == u + 1).all()) for u, t in enumerate(allpcm))
+    q.put((rank, ok_bytes and ok_pcm, int(flat.sum()), gathered, len(table)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,7 +55,7 @@ def test_weight_broadcast_and_sharding_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     res.sort()
-    assert all(r[1] for r in res), "a rank did not receive the packed weights bit-exactly"
+    assert all(r[1] for r in res), "a rank did not receive the packed weights bit-exactly or the PCM gather lost a unit"
     assert res[0][2] == res[1][2] and res[0][4] == res[1][4]
     shards = res[0][3]
     assert sorted(shards[0] + shards[1]) == list(range(9))                 # a partition: every unit once

@@ -80,3 +80,44 @@ def broadcast_weights(spec: ModelSpec, acoustic_dtype: torch.dtype, weights: Opt
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat, src=src)
     return flat, table
+
+
+def gather_pcm(pcm: torch.Tensor, pcm_len: torch.Tensor, unit_ids: Sequence[int], n_units: int) -> Optional[List[torch.Tensor]]:
+    """Collective C2 (optional): bring every rank's PCM to all ranks in global unit order.
+    pcm int16 [B_r][L_r] and pcm_len int32 [B_r] on this rank's device, unit_ids = the global indices of its rows
+    (`shard_units`).  Two fixed-shape all_gathers (lengths + ids, then samples padded to the job-wide maximum):
+    no variable-size exchange, so it maps onto RCCL's ring all_gather; 32 units of 11 s are 17 MB per rank.
+    Returns a list of n_units 1-D int16 CPU tensors (every rank gets it; rank 0 is the usual consumer)."""
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        out: List[Optional[torch.Tensor]] = [None] * n_units
+        for j, u in enumerate(unit_ids):
+            out[u] = pcm[j, : int(pcm_len[j])].cpu()
+        return out
+    world = dist.get_world_size()
+    dev = pcm.device
+    B = torch.tensor([pcm.shape[0], pcm.shape[1]], dtype=torch.int64, device=dev)
+    shapes = [torch.zeros_like(B) for _ in range(world)]
+    dist.all_gather(shapes, B)
+    Bm, Lm = int(max(int(t[0]) for t in shapes)), int(max(int(t[1]) for t in shapes))
+    meta = torch.full((Bm, 2), -1, dtype=torch.int32, device=dev)          # (unit id, length) per row, -1 = padding row
+    meta[: pcm.shape[0], 0] = torch.as_tensor(list(unit_ids), dtype=torch.int32, device=dev)
+    meta[: pcm.shape[0], 1] = pcm_len.to(torch.int32)
+    pad = torch.zeros((Bm, Lm), dtype=torch.int16, device=dev)
+    pad[: pcm.shape[0], : pcm.shape[1]] = pcm
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    pad_b = pad.view(torch.uint8)                          # int16 is not a collective dtype (gloo / RCCL): move the bytes
+    pads_b = [torch.empty_like(pad_b) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    dist.all_gather(pads_b, pad_b)
+    pads = [t.view(torch.int16) for t in pads_b]
+    out = [None] * n_units
+    for mt, pd in zip(metas, pads):
+        mt, pd = mt.cpu(), pd.cpu()
+        for j in range(Bm):
+            u, n = int(mt[j, 0]), int(mt[j, 1])
+            if u >= 0:
+                out[u] = pd[j, :n].clone()
+    if any(o is None for o in out):
+        raise RuntimeError("gather_pcm: some units were produced by no rank")
+    return out
