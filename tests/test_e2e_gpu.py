@@ -202,3 +202,41 @@ def test_bf16_pipeline_through_the_persistent_gemm(hip_tiny):
         n = r["wave"].numel()
         assert int(pcm_len[b]) == n
     eng.close()
+
+
+def test_full_size_model_properties():
+    """BASELINE's full architecture (22 x 1024, 336 M parameters, bf16 acoustic), N = 1600-frame utterances: size-independent
+    properties, no oracle run needed.  (a) splitting the Euler steps across calls is bit-exact; (b) an utterance synthesised
+    inside a ragged batch equals the same utterance alone (different GEMM tilings / packed-row offsets: bf16 tolerance);
+    (c) the PCM is finite, full length, and not silent."""
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec = ModelSpec.full()
+    eng = HipSynth(spec, make_synthetic_weights(spec, seed=9527), acoustic_dtype="bf16", nfe_step=4)
+    la, lt, gf = [144000, 256 * 300 + 40], [256, 120], [1037, 700]
+    batch = make_batch(spec, la, lt, gf, seed=3)
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"])
+    x_once = d["noise"].clone()
+    eng.transformer_steps(x_once, pre, 0, 3)
+    x_split = d["noise"].clone()
+    eng.transformer_steps(x_split, pre, 0, 1)
+    eng.transformer_steps(x_split, pre, 1, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(x_once, x_split)
+    pcm, pcm_len = eng.decode(x_once, pre, max(gf))
+    for b in range(2):
+        sl = int(batch["seq_len"][b])
+        single = dict(audio=batch["audio"][b:b + 1, : la[b]].contiguous(), audio_len=batch["audio_len"][b:b + 1],
+                      ids=batch["ids"][b:b + 1, : lt[b]].contiguous(), text_len=batch["text_len"][b:b + 1],
+                      seq_len=batch["seq_len"][b:b + 1], N=sl, noise=batch["noise"][b:b + 1, :sl].contiguous(), t_gen_max=gf[b])
+        _, xs, pcms, lens_, _ = run_hip(eng, single, 3)
+        ref = xs[0]
+        got = x_once[b, :sl].cpu()
+        rmse = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert rmse < 1e-2, (b, rmse)
+        n = gf[b] * spec.hop_length
+        assert int(pcm_len[b]) == n == int(lens_[0])
+        w = pcm[b, :n].float()
+        assert bool(torch.isfinite(w).all()) and float(w.abs().max()) > 0
+    eng.close()
