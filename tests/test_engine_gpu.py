@@ -162,3 +162,24 @@ def test_engine_from_reference_layout_onnx_archive(tmp_path):
     wb, _ = b.synthesize("Xin chào các bạn.")
     b.cleanup()
     assert np.array_equal(wa, wb)
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the contract's keys (tiny model, 1 step: this checks the plumbing, not speed)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--spec", "tiny", "--steps", "1", "--warmup", "0", "--batch", "4"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["unit"] == "audio-seconds/sec" and d["value"] > 0 and "workload" in d["config"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["cores"] >= 1
