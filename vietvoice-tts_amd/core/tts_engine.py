@@ -153,7 +153,18 @@ class TTSEngine:
         waves: List[Optional[np.ndarray]] = [None] * n_items
         # the device packs ragged rows, so padding is free for the acoustic stages; sorting by length still puts similar
         # lengths into the same batch when a text has more chunks than max_batch_chunks (vocoder planes are padded)
+        groups = []
+        row_cap = eng.max_rows_per_call()          # the packed qkv buffer of one call stays below 2 GiB
         for idx in plan_batches(seq_all, max(1, int(self.config.max_batch_chunks)), pad_frac=1.0):
+            cur, rows = [], 0
+            for i in idx:
+                if cur and rows + seq_all[i] > row_cap:
+                    groups.append(cur)
+                    cur, rows = [], 0
+                cur.append(i)
+                rows += seq_all[i]
+            groups.append(cur)
+        for idx in groups:
             group = [inputs_list[i] for i in idx]
             B = len(group)
             lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)

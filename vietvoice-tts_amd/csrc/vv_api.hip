@@ -378,6 +378,9 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
         Rc += hlen[b]; sum_sq += (double)hlen[b] * hlen[b];
     }
     const size_t R = 2 * Rc;
+    if (R * 3 * (size_t)D * es >= ((size_t)1 << 31))
+        return c->fail(-22, "vv_transformer_steps: %zu packed rows make a %zu-byte qkv buffer; kernels address it with 32-bit byte offsets "
+                            "(< 2 GiB) -- synthesise fewer units per call", R, R * 3 * (size_t)D * es);
     std::vector<int> htab(2 * B + Rc + R);              // row_start[2B] | row_src[Rc] | row_pos[R]
     {
         int* rs = htab.data(); int* src = rs + 2 * B; int* pos = src + Rc;

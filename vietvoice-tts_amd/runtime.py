@@ -264,6 +264,12 @@ class HipSynth:
                 "rope_cos_q": self.rope[0][:N], "rope_sin_q": self.rope[1][:N], "rope_cos_k": self.rope[2][:N],
                 "rope_sin_k": self.rope[3][:N]}
 
+    def max_rows_per_call(self) -> int:
+        """Upper bound on sum(seq_len) of one transformer_steps call: the packed qkv buffer (2 branches x rows x 3D) must stay
+        below 2 GiB (32-bit byte offsets in the kernels)."""
+        es = 2 if self.dt_torch == torch.bfloat16 else 4
+        return ((1 << 31) - 1) // (2 * 3 * self.spec.dim * es)
+
     def transformer_steps(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], step0: int, n_steps: int) -> torch.Tensor:
         """x fp32 [B,N,n_mel] updated in place on the device."""
         B, N, M = x.shape
