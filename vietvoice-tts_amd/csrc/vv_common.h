@@ -81,3 +81,15 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
     bf16x4 v = *(const bf16x4*)p;
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+// non-temporal forms for operands that are streamed exactly once
+template <typename T> __device__ __forceinline__ float4 load4_nt(const T* p);
+template <> __device__ __forceinline__ float4 load4_nt<float>(const float* p) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    const f4 v = __builtin_nontemporal_load((const f4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ float4 load4_nt<bf16>(const bf16* p) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    const u2 w = __builtin_nontemporal_load((const u2*)p);
+    return make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u));
+}

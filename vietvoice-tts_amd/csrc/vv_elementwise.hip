@@ -30,10 +30,10 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
         if (c < n4) {
             v[i] = *(const float4*)(xr + c * 4);
             if (delta) {
-                const float4 d = load4<Td>(delta + (size_t)row * ldd + c * 4);
+                const float4 d = load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
                 v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
                 if (delta2) {                                // (x + delta) + delta2: the order the one-delta-at-a-time protocol adds in
-                    const float4 d2 = load4<Td>(delta2 + (size_t)row * ldd + c * 4);
+                    const float4 d2 = load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4);
                     v[i].x += d2.x; v[i].y += d2.y; v[i].z += d2.z; v[i].w += d2.w;
                 }
                 if (!keep_x) *(float4*)(xr + c * 4) = v[i];
