@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
     for (int i = 0; i < 4; ++i) {
         const int c = lane + i * 64;
         if (c < n4) {
-            v[i] = *(const float4*)(xr + c * 4);
+            v[i] = load4_nt<float>(xr + c * 4);                 // the fp32 stream is far larger than the caches: stream it
             if (delta) {
                 const float4 d = load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
                 v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
                     const float4 d2 = load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4);
                     v[i].x += d2.x; v[i].y += d2.y; v[i].z += d2.z; v[i].w += d2.w;
                 }
-                if (!keep_x) *(float4*)(xr + c * 4) = v[i];
+                if (!keep_x) {
+                    typedef __attribute__((ext_vector_type(4))) float f4;
+                    const f4 w4 = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    __builtin_nontemporal_store(w4, (f4*)(xr + c * 4));
+                }
             }
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
