@@ -82,6 +82,17 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 // non-temporal forms for operands that are streamed exactly once
+template <typename T> __device__ __forceinline__ void store4_nt(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4_nt<float>(float* p, float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    const f4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, (f4*)p);
+}
+template <> __device__ __forceinline__ void store4_nt<bf16>(bf16* p, float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    const bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+    __builtin_nontemporal_store(*(const u2*)&v, (u2*)p);
+}
 template <typename T> __device__ __forceinline__ float4 load4_nt(const T* p);
 template <> __device__ __forceinline__ float4 load4_nt<float>(const float* p) {
     typedef __attribute__((ext_vector_type(4))) float f4;
