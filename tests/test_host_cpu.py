@@ -296,3 +296,27 @@ def test_batching_frontend_plumbing(cpu_engine):
         assert cpu_engine.config.speed == 0.9                         # per-request speed never touches the shared config
     finally:
         fe.close()
+
+
+def test_resample_design_formula_matches_host_mirror():
+    """N3, CPU side: the polyphase formula the GPU resampler evaluates (y[n] = sum_i x[i] * taps[(n + skip) * down - i * up], taps
+    and skip from voice_bank.resample_design) reproduces the host mirror's resampler for the common source rates."""
+    from vietvoice_tts_amd.core.audio_processor import _resample
+    from vietvoice_tts_amd.voice_bank import resample_design
+    rng = np.random.default_rng(4)
+    for src in (48000, 44100, 22050, 16000, 8000):
+        x = (rng.standard_normal(src // 20 + 13) * 3000).astype(np.float32)
+        want = _resample(x, src, 24000)
+        taps, up, down, skip = resample_design(src, 24000)
+        n_out = -(-(x.size * up) // down)
+        assert n_out == want.size
+        got = np.zeros(n_out)
+        xd = x.astype(np.float64)
+        for n in range(n_out):
+            pos = (n + skip) * down
+            i_hi = min(pos // up, x.size - 1)
+            lo = pos - len(taps) + 1
+            i_lo = 0 if lo <= 0 else -(-lo // up)
+            i = np.arange(i_lo, i_hi + 1)
+            got[n] = np.dot(xd[i], taps[pos - i * up])
+        assert np.abs(got.astype(np.float32) - want).max() <= 1e-3 + 1e-6 * np.abs(want).max()
