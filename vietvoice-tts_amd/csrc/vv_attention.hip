@@ -18,7 +18,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_T = 8.0f;              // bf16 kernel, log2 domain: tolerate 2^8 of head-room before re-referencing
+constexpr float RESCALE_SUM = 256.0f;          // bf16 kernel: a half-row sum of p above 2^8 sends the tile to the careful path
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // max / sum across the two 32-lane halves with the gfx950 half swap (one v_permlane32_swap instead of a ds_bpermute round trip)
@@ -140,37 +140,62 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // per key block) instead of 32 VALU fmas per tile -- the loop is VALU-bound (profiles/r01/attention_notes.md).
         // s[kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32
         f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
-#pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
-            }
-        }
         const int kbase = kt * 64;
-        if (kbase + 64 > kv_len) {
+        auto scores = [&]() {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+                }
+            }
+            if (kbase + 64 > kv_len) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (key >= kv_len) s[kb][r] = NEG_BIG;
+                    }
+            }
+        };
+        // p = 2^s' in place, returns this half-wave's partial row sum.  Single f32 instructions on purpose -- packed f32 VALU
+        // (v_pk_fma/add_f32) issues slowly beside MFMAs on gfx950 (measured 1011 -> 989 us when unpacked).
+        auto exps = [&]() -> float {
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};          // four independent sum chains
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= kv_len) s[kb][r] = NEG_BIG;
+                    const float pv = fast_exp2(s[kb][r]);
+                    ps[r & 3] += pv;
+                    s[kb][r] = pv;
                 }
+            return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        };
+        // Online softmax with a SPECULATIVE tile: the exponentials are taken against the stale reference m_eff without looking
+        // for the row max first (21 VALU instructions per tile); the partial row sums then tell whether that was safe -- an
+        // element above 2^8 (or an overflow to inf) puts its half-row sum above 256.  Only then (and on the first tile) the
+        // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
+        // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
+        // which path ran.
+        float psum = 0.f;
+        bool redo = kt == 0;
+        if (!redo) {
+            scores();
+            psum = exps();
+            redo = __any(!(psum <= RESCALE_SUM));
         }
-        // ---- online softmax (query on the lane; the other half-wave holds the other 32 keys)
-        float mx = s[0][0];
+        if (redo) {
+            scores();
+            float mx = s[0][0];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
-        // Deferred re-reference (wave-uniform branch): m_eff moves on the first tile and then only when some row's shifted
-        // max passes RESCALE_T (2^8 of head-room).  Softmax is invariant to the subtracted constant, so a stale m_eff only
-        // means p <= 256 instead of <= 1.  m_eff is kept bf16-representable so that the MFMA subtracts it exactly and O, l
-        // and p always see the same reference.
-        if (kt == 0 || __any(mx > RESCALE_T)) {
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
             const float m_new = bf16_round(kt == 0 ? mx : m_eff + fmaxf(mx, 0.f));
             const float d = m_new - m_eff;                     // exact: both are bf16 values
             if (kt != 0) {                                     // O and l are zero on the first tile
@@ -187,19 +212,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 for (int r = 0; r < 16; ++r) s[kb][r] -= d;    // this tile was shifted by the old reference
             m_eff = m_new;
             q_ext = make_q_ext(-m_new, h);
+            psum = exps();
         }
-        // p = 2^s' : single f32 instructions on purpose -- packed f32 VALU (v_pk_fma/add_f32) issues slowly beside MFMAs on
-        // gfx950 (measured 1011 -> 989 us on the benchmark shape when unpacked)
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};          // four independent sum chains
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(s[kb][r]);
-                ps[r & 3] += pv;
-                s[kb][r] = pv;
-            }
-        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        l_run += psum;
 
         // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
 #pragma unroll
