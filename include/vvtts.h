@@ -95,6 +95,17 @@ int vv_transformer_steps(vv_ctx* ctx, int B, int N, const int32_t* seq_len, floa
 int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
               int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream);
 
+/* The same decode stage with every intermediate carved from a CALLER-OWNED device block `ws` (256-byte aligned,
+ * >= vv_decode_ws_bytes bytes) instead of the context arena.  The context arena may be reallocated by any later call
+ * that needs more bytes (vv_ws_generation counts those moves); a launch sequence captured into a hipGraph
+ * (BASELINE.json configs[4], "hipGraph-captured vocoder step") must therefore run through vv_decode_into so that
+ * nothing it points at can move while the graph lives.  No reference counterpart (the reference never captures). */
+int vv_decode_ws_bytes(vv_ctx* ctx, int B, int t_gen_max, uint64_t* bytes);
+int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
+                   int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* ws, uint64_t ws_bytes,
+                   void* stream);
+uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
+
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
 #define VV_PROF_GEMM 0
 #define VV_PROF_ATTN 1

@@ -30,17 +30,54 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from vietvoice_tts_amd.model_spec import ModelSpec, mel_filterbank, time_grid
+import numpy as np
+
+# The oracle imports NOTHING from the product package: the constant tables below (mel filterbank, sway-sampled
+# time grid, sinusoidal time table, rope / text position tables, Hann window) are its own float64 closed forms,
+# written independently of vietvoice_tts_amd/model_spec.py and pack.py.  tests/test_oracle_tables_cpu.py asserts
+# that the two sets agree, so a wrong table on either side is visible.  ``spec`` is duck-typed (any object with
+# the architecture constants of SURVEY.md 8(a)); weights are a plain name -> tensor dict handed in by the caller.
+
+
+def oracle_time_grid(nfe_step: int, sway_coef: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Sway-sampled ODE grid t_i = u_i + s*(cos(pi/2 u_i) - 1 + u_i), u_i = i/(nfe-1); the reference runs
+    nfe_step-1 evaluations (core/tts_engine.py:157-159).  float64, then fp32."""
+    u = np.arange(nfe_step, dtype=np.float64) / float(nfe_step - 1)
+    t = u + sway_coef * (np.cos(0.5 * np.pi * u) - 1.0 + u)
+    return torch.from_numpy(t[:-1].astype(np.float32)), torch.from_numpy(np.diff(t).astype(np.float32))
+
+
+def oracle_mel_filterbank(sample_rate: int, n_fft: int, n_mel: int) -> torch.Tensor:
+    """HTK mel scale, triangular, un-normalised, f_min 0 .. f_max sr/2: (n_fft/2+1, n_mel)."""
+    def hz2mel(f):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+
+    def mel2hz(m):
+        return 700.0 * (np.power(10.0, m / 2595.0) - 1.0)
+    edges = mel2hz(np.linspace(hz2mel(0.0), hz2mel(sample_rate / 2.0), n_mel + 2))      # n_mel+2 band edges in Hz
+    bins = np.arange(n_fft // 2 + 1, dtype=np.float64) * (float(sample_rate // 2) / (n_fft // 2))
+    fb = np.zeros((n_fft // 2 + 1, n_mel), dtype=np.float64)
+    for m in range(n_mel):
+        lo, ce, hi = edges[m], edges[m + 1], edges[m + 2]
+        rise = (bins - lo) / (ce - lo)
+        fall = (hi - bins) / (hi - ce)
+        fb[:, m] = np.maximum(0.0, np.minimum(rise, fall))
+    return torch.from_numpy(fb.astype(np.float32))
+
+
+def oracle_hann(win_length: int) -> torch.Tensor:
+    n = np.arange(win_length, dtype=np.float64)
+    return torch.from_numpy((0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)).astype(np.float32))     # periodic
 
 
 class Oracle:
-    def __init__(self, spec: ModelSpec, weights: Dict[str, torch.Tensor], nfe_step: int = 32):
+    def __init__(self, spec, weights: Dict[str, torch.Tensor], nfe_step: int = 32):
         self.spec = spec
         self.w = {k: v.to(torch.float32) for k, v in weights.items()}
         self.nfe_step = nfe_step
-        self.t_grid, self.dt_grid = time_grid(nfe_step, spec.sway_coef)
-        self.fb = mel_filterbank(spec)
-        self.window = torch.hann_window(spec.win_length, periodic=True, dtype=torch.float32)
+        self.t_grid, self.dt_grid = oracle_time_grid(nfe_step, spec.sway_coef)
+        self.fb = oracle_mel_filterbank(spec.sample_rate, spec.n_fft, spec.n_mel)
+        self.window = oracle_hann(spec.win_length)
 
     # ------------------------------------------------------------------ preprocess
     def mel(self, audio_i16: torch.Tensor) -> torch.Tensor:
@@ -54,10 +91,10 @@ class Oracle:
         return mel.clamp(min=1e-5).log().t().contiguous()
 
     def text_pos_table(self, n: int) -> torch.Tensor:
+        """[cos | sin] halves of pos * 10000^(-2i/d), float64 then fp32."""
         d = self.spec.text_dim
-        freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32)[: d // 2] / d))
-        ang = torch.outer(torch.arange(n, dtype=torch.float32), freqs)
-        return torch.cat([ang.cos(), ang.sin()], dim=-1)
+        ang = np.arange(n, dtype=np.float64)[:, None] * np.power(10000.0, -np.arange(0, d, 2, dtype=np.float64) / d)[None, :]
+        return torch.from_numpy(np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32))
 
     def grn(self, x: torch.Tensor, gamma, beta) -> torch.Tensor:
         gx = torch.norm(x, p=2, dim=0, keepdim=True)            # over the sequence, per channel
@@ -86,12 +123,15 @@ class Oracle:
         return x
 
     def rope_tables(self, n: int):
+        """(cos_q, sin_q, cos_k, sin_k), each (n, head_dim): interleaved pairs (2i, 2i+1) share the angle
+        pos * theta^(-2i/head_dim); the q tables carry the softmax scale head_dim^-0.5.  float64 then fp32."""
         s = self.spec
-        inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2, dtype=torch.float32) / s.head_dim))
-        ang = torch.outer(torch.arange(n, dtype=torch.float32), inv)
-        ang = ang.repeat_interleave(2, dim=-1)                  # (n, head_dim), pairs (2i,2i+1)
-        scale = s.head_dim ** -0.5
-        return ang.cos() * scale, ang.sin() * scale, ang.cos(), ang.sin()
+        hd = s.head_dim
+        ang = np.arange(n, dtype=np.float64)[:, None] * np.power(float(s.rope_theta), -np.arange(0, hd, 2, dtype=np.float64) / hd)[None, :]
+        ang = np.repeat(ang, 2, axis=1)
+        scale = float(hd) ** -0.5
+        f = lambda a: torch.from_numpy(a.astype(np.float32))
+        return f(np.cos(ang) * scale), f(np.sin(ang) * scale), f(np.cos(ang)), f(np.sin(ang))
 
     def preprocess(self, audio_i16: torch.Tensor, text_ids: torch.Tensor, max_duration: int,
                    noise: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -118,9 +158,8 @@ class Oracle:
     def time_embed(self, step: int) -> torch.Tensor:
         s, w = self.spec, self.w
         half = s.time_freq_dim // 2
-        emb = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
-        emb = 1000.0 * self.t_grid[step] * emb
-        emb = torch.cat([emb.sin(), emb.cos()], dim=-1)
+        arg = 1000.0 * float(self.t_grid[step]) * np.exp(-np.arange(half, dtype=np.float64) * (math.log(10000.0) / (half - 1)))
+        emb = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32))       # [sin | cos], float64 then fp32
         h = F.silu(F.linear(emb, w["time.mlp1.weight"], w["time.mlp1.bias"]))
         return F.linear(h, w["time.mlp2.weight"], w["time.mlp2.bias"])
 

@@ -34,6 +34,8 @@ def load_reference():
     sys.modules.setdefault("pydub", pd)
     class _Any(types.ModuleType):
         def __getattr__(self, _n):
+            if _n.startswith("__"):                    # module introspection (__file__, __path__, ...) must not see a stub
+                raise AttributeError(_n)
             return type("Stub", (), {})
     sys.modules.setdefault("onnxruntime", _Any("onnxruntime"))
     pkg = types.ModuleType("refcore")

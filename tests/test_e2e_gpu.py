@@ -156,6 +156,37 @@ def test_graph_captured_decode_matches_eager(hip_tiny, tiny_setup):
         assert torch.equal(len_e, len_g) and torch.equal(pcm_e, pcm_g)
 
 
+def test_captured_decode_survives_workspace_growth(tiny_setup):
+    """a captured vocoder graph must stay valid when a LATER, larger call reallocates the context arena.
+    Capture at a small shape, force the arena to move (vv_ws_generation changes) with a much larger batch, then replay the
+    old graph with fresh inputs and compare with the eager decode, bit for bit."""
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec, w, _ = tiny_setup
+    eng = HipSynth(spec, w, acoustic_dtype="fp32", nfe_step=4)          # its own context: the arena starts small
+    small = make_batch(spec, [256 * 16, 256 * 16], [20, 14], [12, 9], seed=41)
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in small.items()}
+    pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"])
+    x = d["noise"].clone()
+    eng.transformer_steps(x, pre, 0, 2)
+    graphed = eng.capture_decode(2, d["N"], d["t_gen_max"])
+    pcm_g0 = graphed(x, pre["ref_signal_len"], pre["seq_len"])[0].clone()
+    gen0 = int(eng.lib.vv_ws_generation(eng.ctx))
+    big = make_batch(spec, [256 * 40] * 6, [40] * 6, [300] * 6, seed=42)                 # ~25x the decode workspace
+    db = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in big.items()}
+    eng.synthesize_batch(db["audio"], db["audio_len"], db["ids"], db["text_len"], db["seq_len"], db["N"], db["noise"], db["t_gen_max"], n_steps=1)
+    torch.cuda.synchronize()
+    assert int(eng.lib.vv_ws_generation(eng.ctx)) > gen0, "the larger call was meant to move the arena"
+    for scale in (1.0, -0.7):
+        xin = x * scale
+        pcm_g, len_g = graphed(xin, pre["ref_signal_len"], pre["seq_len"])
+        pcm_g = pcm_g.clone()
+        pcm_e, len_e = eng.decode(xin, pre, d["t_gen_max"])
+        torch.cuda.synchronize()
+        assert torch.equal(len_e, len_g) and torch.equal(pcm_e, pcm_g)
+    assert torch.equal(pcm_g0, graphed(x, pre["ref_signal_len"], pre["seq_len"])[0])
+    eng.close()
+
+
 def test_bucketed_decode_equals_one_batch(hip_tiny, tiny_setup):
     """Ragged batches decode in length buckets (padded vocoder planes): same PCM as the single padded decode, bit for bit."""
     spec, _, _ = tiny_setup

@@ -320,3 +320,34 @@ def test_resample_design_formula_matches_host_mirror():
             i = np.arange(i_lo, i_hi + 1)
             got[n] = np.dot(xd[i], taps[pos - i * up])
         assert np.abs(got.astype(np.float32) - want).max() <= 1e-3 + 1e-6 * np.abs(want).max()
+
+
+def test_crossfade_stream_equals_buffered_join_including_clipped_chunks():
+    """N4 state machine: every raw chunk is clip-repaired ONCE and only the cross-fade tail is kept, so chunks
+    whose samples reach +-32767 (directly, or after the 0.7..1.5 level-matching gain wraps in int16) do not rescale
+    audio that was already emitted.  Checked against the buffered join, itself pinned by reference-generated golden
+    vectors (test_crossfade_golden), on the golden inputs and on chunk sets built to clip."""
+    from vietvoice_tts_amd.core.audio_processor import AudioProcessor, CrossfadeStream
+    rng = np.random.default_rng(5)
+    sets = []
+    for key, n, sr, dur in GOLD["crossfade"]:
+        sets.append(([NPZ[f"{key}_in_{j}"] for j in range(n)], sr, dur))
+    loud = (rng.standard_normal(9000) * 9000).clip(-32768, 32767).astype(np.int16)
+    loud[100] = 32767
+    quiet = (rng.standard_normal(8000) * 400).astype(np.int16)
+    hot = (rng.standard_normal(7000) * 14000).clip(-32768, 32767).astype(np.int16)       # x1.5 gain wraps in int16
+    sets += [([quiet, loud, quiet, hot, loud], 24000, 0.1), ([hot, quiet, hot], 24000, 0.05), ([loud, loud[:1500], hot], 24000, 0.1),
+             ([quiet[:300], loud[:200], hot[:5000]], 24000, 0.1), ([loud.reshape(1, 1, -1), hot.reshape(1, 1, -1)], 16000, 0.0)]
+    for ws, sr, dur in sets:
+        want = np.asarray(AudioProcessor.concatenate_with_crossfade_improved([w.copy() for w in ws], dur, sr))
+        js = CrossfadeStream(len(ws), dur, sr)
+        blocks, emitted_before = [], 0
+        for w in ws:
+            b = js.push(w.copy())
+            blocks.append(b)
+            emitted_before += b.size
+            assert emitted_before <= want.size
+        got = np.concatenate(blocks)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        if len(ws) > 2 and dur > 0:
+            assert blocks[0].size > 0 or ws[0].size <= int(dur * sr)       # audio really is emitted before the last chunk

@@ -32,7 +32,24 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """ablate=True builds libvvtts_hip_ablate.so with -DVV_GEMM_ABLATE (the timing-only GEMM ablation bits read from
+    VV_GEMM_DBG): an A/B library for tools/gemm_bench.py, selected with VVTTS_LIB.  The shipped library has no such path."""
+    global OBJ, LIB
+    if ablate:
+        obj_dir, lib = os.path.join(HERE, "build", "ablate"), os.path.join(HERE, "libvvtts_hip_ablate.so")
+        saved = (OBJ, LIB, list(FLAGS))
+        OBJ, LIB = obj_dir, lib
+        FLAGS.append("-DVV_GEMM_ABLATE")
+        try:
+            return _build(force, verbose)
+        finally:
+            OBJ, LIB = saved[0], saved[1]
+            FLAGS[:] = saved[2]
+    return _build(force, verbose)
+
+
+def _build(force: bool, verbose: bool) -> str:
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "vvtts.h"))
@@ -62,4 +79,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))

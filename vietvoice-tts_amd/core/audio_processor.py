@@ -180,3 +180,52 @@ class AudioProcessor:
             mixed = (tail.astype(np.float32) * np.cos(theta) ** 2 + head.astype(np.float32) * np.sin(theta) ** 2).astype(np.int16)
             out = np.concatenate([out[:-n], mixed, nxt[n:]])
         return out
+
+
+class CrossfadeStream:
+    """Incremental form of ``concatenate_with_crossfade_improved`` for streaming output.
+
+    The buffered join (reference core/audio_processor.py:122-192) repairs clipping once per RAW chunk and then, per
+    junction, rewrites only the last ``n = min(cross_fade, len(out), len(next))`` samples of what has been joined.
+    This class keeps exactly that state -- the not-yet-final tail of ``out`` and its total length -- so every chunk goes
+    through ``fix_clipped_audio`` once, already-emitted samples are never touched again, and the concatenation of the
+    blocks returned by ``push`` equals the buffered result sample for sample.  ``n_chunks`` is needed up front because
+    the buffered function returns a single chunk untouched (no clip repair when there is nothing to join)."""
+
+    def __init__(self, n_chunks: int, cross_fade_duration: float, sample_rate: int):
+        self.n_chunks = int(n_chunks)
+        self.cf = int(cross_fade_duration * sample_rate) if cross_fade_duration > 0 else 0
+        self.fade = cross_fade_duration > 0
+        self.held = None          # un-emitted tail of the joined signal
+        self.total = 0            # samples joined so far (emitted + held)
+        self.seen = 0
+
+    def push(self, wave: np.ndarray) -> np.ndarray:
+        """Add the next raw chunk; returns the samples that became final (possibly empty)."""
+        self.seen += 1
+        last = self.seen >= self.n_chunks
+        w = np.asarray(wave).reshape(-1)
+        if self.n_chunks == 1:
+            return w
+        nxt = AudioProcessor.fix_clipped_audio(w)
+        if self.held is None:
+            joined = nxt
+        else:
+            n = min(self.cf, self.total, len(nxt)) if self.fade else 0
+            if n <= 0:
+                joined = np.concatenate([self.held, nxt])
+            else:
+                tail, head = self.held[-n:], nxt[:n]
+                rms_prev = np.sqrt(np.mean(tail.astype(np.float32) ** 2))
+                rms_next = np.sqrt(np.mean(head.astype(np.float32) ** 2))
+                if rms_prev > 100 and rms_next > 100:
+                    gain = np.clip(rms_prev / rms_next, 0.7, 1.5)
+                    nxt = (nxt.astype(np.float32) * gain).astype(np.int16)
+                    head = nxt[:n]
+                theta = np.linspace(0, np.pi / 2, n)
+                mixed = (tail.astype(np.float32) * np.cos(theta) ** 2 + head.astype(np.float32) * np.sin(theta) ** 2).astype(np.int16)
+                joined = np.concatenate([self.held[:-n], mixed, nxt[n:]])
+        self.total += len(joined) - (0 if self.held is None else len(self.held))
+        keep = 0 if last else min(self.cf, len(joined))       # the next junction may rewrite at most the last cf samples
+        out, self.held = joined[: len(joined) - keep], joined[len(joined) - keep:]
+        return np.ascontiguousarray(out)

@@ -163,11 +163,12 @@ class ModelSessionManager:
                       emotion: Optional[str] = None, sample_iteration: Optional[int] = None,
                       reference_audio: Optional[str] = None, reference_text: Optional[str] = None) -> Tuple[object, str]:
         """-> (reference audio path or WAV bytes, reference text); semantics of model.py:137-214."""
+        # falsy arguments fall back to the config defaults, and the defaulted values are what the error text reports (:147-150,213)
+        gender, group = gender or self.config.gender, group or self.config.group
+        area, emotion = area or self.config.area, emotion or self.config.emotion
         wanted = {}
-        for key, value, allowed in (("gender", gender or self.config.gender, MODEL_GENDER),
-                                    ("group", group or self.config.group, MODEL_GROUP),
-                                    ("area", area or self.config.area, MODEL_AREA),
-                                    ("emotion", emotion or self.config.emotion, MODEL_EMOTION)):
+        for key, value, allowed in (("gender", gender, MODEL_GENDER), ("group", group, MODEL_GROUP),
+                                    ("area", area, MODEL_AREA), ("emotion", emotion, MODEL_EMOTION)):
             if value is not None:
                 if value not in allowed:
                     raise ValueError(f"Invalid {key}: {value}. Must be one of {allowed}")

@@ -243,8 +243,9 @@ class TTSEngine:
         """Generator of int16 PCM blocks: audio is emitted as soon as a group of ``chunks_per_step``
         chunks is synthesised instead of after the whole text (the reference buffers everything, api/app.py:59-65).
         Overlap-save: the improved cross-fade only rewrites the last ``cross_fade_duration`` of what has been joined
-        so far (audio_processor.py:122-192), so everything before that tail is final and can be yielded; the
-        concatenation of all yielded blocks equals ``synthesize(text)`` sample for sample."""
+        so far (audio_processor.py:122-192), so everything before that tail is final and can be yielded.  The joiner
+        (``CrossfadeStream``) keeps only that tail: each raw chunk is clip-repaired once, emitted samples are never
+        revisited, and the concatenation of all yielded blocks equals ``synthesize(text)`` sample for sample."""
         speed = self.config.speed
         ref_audio, ref_text = self.model_session_manager.select_sample(gender, group, area, emotion, sample_iteration,
                                                                        reference_audio, reference_text)
@@ -252,8 +253,8 @@ class TTSEngine:
             with self._lock:
                 inputs_list = self._prepare_inputs(ref_audio, ref_text, text, speed=speed)
             self._last_plan = [int(i[2][0]) for i in inputs_list]
-            cf = int(self.config.cross_fade_duration * self.config.sample_rate)
-            joined, emitted = None, 0
+            from .audio_processor import CrossfadeStream
+            joiner = CrossfadeStream(len(inputs_list), self.config.cross_fade_duration, self.config.sample_rate)
             step = max(1, int(chunks_per_step))
             for lo in range(0, len(inputs_list), step):
                 with self._lock:
@@ -261,15 +262,10 @@ class TTSEngine:
                         waves = self._synthesize_device(inputs_list[lo: lo + step])
                     else:
                         waves = self._synthesize_sessions(inputs_list[lo: lo + step])
-                for w in waves:
-                    parts = [w] if joined is None else [joined, w]
-                    joined = self.audio_processor.concatenate_with_crossfade_improved(parts, self.config.cross_fade_duration,
-                                                                                      self.config.sample_rate)
-                last = lo + step >= len(inputs_list)
-                upto = len(joined) if last else max(emitted, len(joined) - cf)
-                if upto > emitted:
-                    yield np.ascontiguousarray(joined[emitted:upto])
-                    emitted = upto
+                blocks = [joiner.push(w) for w in waves]
+                block = np.concatenate(blocks) if len(blocks) > 1 else blocks[0]
+                if block.size:
+                    yield block
         except Exception as e:
             raise RuntimeError(f"Speech synthesis failed: {str(e)}")
 

@@ -37,8 +37,11 @@ struct vv_ctx {
     float* modtab = nullptr;            // [depth][n_steps][6D]
     float* fintab = nullptr;            // [n_steps][2D]
     // workspace arena
-    char* ws = nullptr;
-    size_t ws_cap = 0, ws_off = 0;
+    char* ws = nullptr;                 // context-owned arena: may MOVE when a later call needs more bytes (ensure_ws)
+    size_t ws_cap = 0;
+    char* ar = nullptr;                 // active arena of the current call: ws, or a caller-owned block (vv_decode_into)
+    size_t ar_cap = 0, ar_off = 0;
+    uint64_t ws_generation = 0;         // bumped whenever ws is reallocated
     int* d_mult = nullptr;              // decode length multipliers
     // profiling
     bool prof = false;
@@ -95,18 +98,28 @@ struct Prof {
 };
 
 int ensure_ws(vv_ctx* c, size_t bytes) {
-    if (bytes <= c->ws_cap) { c->ws_off = 0; return 0; }
-    if (c->ws) { hipDeviceSynchronize(); hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
-    const size_t want = align_up(bytes + bytes / 16, 1 << 20);
-    hipError_t e = hipMalloc((void**)&c->ws, want);
-    if (e != hipSuccess) return c->fail(-12, "workspace hipMalloc(%zu MiB): %s", want >> 20, hipGetErrorString(e));
-    c->ws_cap = want; c->ws_off = 0;
+    if (bytes > c->ws_cap) {
+        if (c->ws) { hipDeviceSynchronize(); hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
+        const size_t want = align_up(bytes + bytes / 16, 1 << 20);
+        hipError_t e = hipMalloc((void**)&c->ws, want);
+        if (e != hipSuccess) return c->fail(-12, "workspace hipMalloc(%zu MiB): %s", want >> 20, hipGetErrorString(e));
+        c->ws_cap = want;
+        ++c->ws_generation;
+    }
+    c->ar = c->ws; c->ar_cap = c->ws_cap; c->ar_off = 0;
+    return 0;
+}
+// A caller-owned block as the arena of one call (memory that can never move: what a captured hipGraph must point into).
+int use_ws(vv_ctx* c, void* block, size_t have, size_t need) {
+    if ((uintptr_t)block % 256) return c->fail(-22, "workspace block must be 256-byte aligned");
+    if (have < need) return c->fail(-22, "workspace block too small: %zu < %zu bytes", have, need);
+    c->ar = (char*)block; c->ar_cap = have; c->ar_off = 0;
     return 0;
 }
 template <typename T> T* carve(vv_ctx* c, size_t n) {
-    c->ws_off = align_up(c->ws_off, 256);
-    T* p = (T*)(c->ws + c->ws_off);
-    c->ws_off += n * sizeof(T);
+    c->ar_off = align_up(c->ar_off, 256);
+    T* p = (T*)(c->ar + c->ar_off);
+    c->ar_off += n * sizeof(T);
     return p;
 }
 struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + bytes; } };
@@ -490,8 +503,28 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
 }
 
 // --------------------------------------------------------------------------------------- decode
-int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
-              int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream) {
+static size_t decode_need(const vv_ctx* c, int B, int t_gen_max) {
+    const vv_model_cfg& g = c->cfg;
+    const int nu = g.voc_n_up;
+    size_t big = (size_t)g.voc_pre_ch * t_gen_max, T = t_gen_max;
+    int ch = g.voc_pre_ch;
+    for (int s = 0; s < nu; ++s) { T *= g.voc_up_rates[s]; ch /= 2; big = std::max(big, (size_t)ch * T); }
+    Need nd; nd.add(4ull * B * g.n_mel * t_gen_max);
+    for (int i = 0; i < 5; ++i) nd.add(4ull * B * big);
+    nd.add(4ull * (nu + 1) * B);
+    return nd.b;
+}
+
+int vv_decode_ws_bytes(vv_ctx* c, int B, int t_gen_max, uint64_t* bytes) {
+    if (!c || !bytes || B < 1 || t_gen_max < 1) return c ? c->fail(-22, "vv_decode_ws_bytes: bad arguments") : -22;
+    *bytes = (uint64_t)align_up(decode_need(c, B, t_gen_max), 256);
+    return 0;
+}
+
+uint64_t vv_ws_generation(const vv_ctx* c) { return c ? c->ws_generation : 0; }
+
+static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
+                       int ld_pcm, int32_t* pcm_len, float* wave_f32, void* ext_ws, uint64_t ext_bytes, void* stream) {
     if (!c) return -22;
     if (!c->finalized) return c->fail(-1, "vv_decode: weights not finalized");
     if (B < 1 || N < 1 || !x || !ref_len || !seq_len || !pcm || !pcm_len || t_gen_max < 1 || t_gen_max > N)
@@ -507,10 +540,9 @@ int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, c
     size_t big = 0;
     for (int s = 0; s < nu; ++s) { Ts[s + 1] = Ts[s] * g.voc_up_rates[s]; Cs[s + 1] = Cs[s] / 2; big = std::max(big, (size_t)Cs[s + 1] * Ts[s + 1]); }
     big = std::max(big, (size_t)Cs[0] * Ts[0]);
-    Need nd; nd.add(4ull * B * M * Ts[0]);
-    for (int i = 0; i < 5; ++i) nd.add(4ull * B * big);
-    nd.add(4ull * (nu + 1) * B);
-    if (int r = ensure_ws(c, nd.b)) return r;
+    const size_t need = decode_need(c, B, t_gen_max);
+    if (ext_ws) { if (int r = use_ws(c, ext_ws, (size_t)ext_bytes, need)) return r; }
+    else if (int r = ensure_ws(c, need)) return r;
     float* v0 = carve<float>(c, (size_t)B * M * Ts[0]);
     float* buf[5];
     for (int i = 0; i < 5; ++i) buf[i] = carve<float>(c, (size_t)B * big);
@@ -574,6 +606,21 @@ int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, c
                               lens + (size_t)nu * B, st, &m__));
     }
     return 0;
+}
+
+int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
+              int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream) {
+    return decode_impl(c, B, N, x, ref_len, seq_len, t_gen_max, pcm, ld_pcm, pcm_len, wave_f32, nullptr, 0, stream);
+}
+
+// Same stage with every intermediate in a CALLER-OWNED block of vv_decode_ws_bytes() bytes: nothing the launches point at can
+// be moved by a later call that grows the context arena, so the launch sequence may be captured into a hipGraph and replayed
+// for the lifetime of that block (reference has no counterpart; BASELINE.json configs[4] "hipGraph-captured vocoder step").
+int vv_decode_into(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
+                   int ld_pcm, int32_t* pcm_len, float* wave_f32, void* ws, uint64_t ws_bytes, void* stream) {
+    if (!c) return -22;
+    if (!ws) return c->fail(-22, "vv_decode_into: null workspace block");
+    return decode_impl(c, B, N, x, ref_len, seq_len, t_gen_max, pcm, ld_pcm, pcm_len, wave_f32, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------ profiling

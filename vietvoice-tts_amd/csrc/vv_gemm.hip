@@ -18,7 +18,9 @@
 // XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
 #include "vv_common.h"
 #include "vv_kernels.h"
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -43,8 +45,17 @@ struct EpiArgs {
     int seq_n;
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
     int rope_dim;
-    int dbg;     // timing-only ablations (tools/gemm_bench.py): bit0 = no wait/barrier, bit1 = no loads in the loop
+#ifdef VV_GEMM_ABLATE
+    int dbg;     // timing-only ablations, A/B build for tools/gemm_bench.py ONLY (libvvtts_hip_ablate.so, selected with VVTTS_LIB):
+                 // bit0 = no wait/barrier, bit1 = no loads in the loop, 4/8 = kernel choice, 128/512/1024 = epilogue variants
+#endif
 };
+// The shipped library has no ablation path: VV_DBG folds to the constant 0 and every branch on it is compiled out.
+#ifdef VV_GEMM_ABLATE
+#define VV_DBG(e) ((e).dbg)
+#else
+#define VV_DBG(e) 0
+#endif
 
 // fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
 __device__ __forceinline__ float fast_sigmoid(float x) {
@@ -154,11 +165,11 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
         for (int kt = 0; kt < nk; ++kt) {
-            if (!(e.dbg & 1)) {
+            if (!(VV_DBG(e) & 1)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
-            if (kt + 1 < nk && !(e.dbg & 2)) stage(kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nk && !(VV_DBG(e) & 2)) stage(kt + 1, (kt + 1) & 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         }
         ++G;
         for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n);
-        stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && !e.dbg && bm + 256 <= M && bn + 256 <= e.n_store;
+        stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && !VV_DBG(e) && bm + 256 <= M && bn + 256 <= e.n_store;
 
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
             // chunk index XOR (row & 7)) so that global stores are whole 128-byte rows.  The unit slots are NOT
             // touched: the next tile's first units are landing there.
             char* stg = smem + 8 * UNIT + wave * 4096;
-            if (!(e.dbg & 512))
+            if (!(VV_DBG(e) & 512))
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int mh = ps >> 1;
@@ -564,8 +575,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
                     const int m = bm + g * 128 + ps * 32 + lr;
                     const int n0 = bn + wc * 64 + ch * 8;
-                    if (m < M && n0 < e.n_store && !(e.dbg & 128)) {
-                        if (e.dbg & 1024) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
+                    if (m < M && n0 < e.n_store && !(VV_DBG(e) & 128)) {
+                        if (VV_DBG(e) & 1024) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
                         else {   // streamed once, read by the next kernel from HBM anyway
                             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
                             const u32x4 vv = {val.x, val.y, val.z, val.w};
@@ -599,20 +610,41 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
 }
 
+// One-time per-(kernel, device) setup: the dynamic-LDS opt-in is a per-device function attribute, and contexts on several
+// GPUs (or several threads) may reach a launcher's first call at the same time.
+struct KernelSetup {
+    std::mutex mu;
+    std::atomic<uint64_t> done{0};     // bit d = device d configured
+    int n_cu[64] = {};
+    hipError_t ensure(const void* kern, int lds_bytes, int* cu_out) {
+        int dev = 0;
+        hipError_t he = hipGetDevice(&dev);
+        if (he != hipSuccess) return he;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!(done.load(std::memory_order_acquire) >> dev & 1)) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!(done.load(std::memory_order_relaxed) >> dev & 1)) {
+                he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (he != hipSuccess) return he;
+                int cu = 0;
+                if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+                n_cu[dev] = cu / 8 * 8;
+                done.fetch_or(1ull << dev, std::memory_order_release);
+            }
+        }
+        if (cu_out) *cu_out = n_cu[dev];
+        return hipSuccess;
+    }
+};
+
 template <int MODE, typename To>
 hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                      hipStream_t st) {
     constexpr int LDS = 2 * 4 * 128 * 128 + 8 * 4096;          // 160 KiB: the whole CU
-    static bool attr_set = false;
-    static int n_cu = 256;
+    static KernelSetup setup;
     auto kern = gemm_pp_kernel<MODE, To>;
-    if (!attr_set) {
-        hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (he != hipSuccess) return he;
-        int dev = 0; hipGetDevice(&dev);
-        hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) n_cu = pr.multiProcessorCount / 8 * 8;
-        attr_set = true;
-    }
+    int n_cu = 256;
+    if (hipError_t he = setup.ensure((const void*)kern, LDS, &n_cu); he != hipSuccess) return he;
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     const int total = m_tiles * n_tiles;
     const int grid = std::min(n_cu, (total + 7) / 8 * 8);      // one persistent workgroup per CU, a multiple of the 8 XCD labels
@@ -625,13 +657,9 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
                     hipStream_t st) {
     constexpr int BT = CFG ? 256 : 128;
     constexpr int LDS = 2 * 2 * BT * 128;
-    static bool attr_set = false;
+    static KernelSetup setup;
     auto kern = gemm_kernel<T, MODE, To, CFG>;
-    if (!attr_set) {
-        hipError_t he = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (he != hipSuccess) return he;
-        attr_set = true;
-    }
+    if (hipError_t he = setup.ensure((const void*)kern, LDS, nullptr); he != hipSuccess) return he;
     const int m_tiles = (M + BT - 1) / BT, n_tiles = N / BT;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
     kern<<<grid, CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), LDS, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
@@ -643,11 +671,12 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
                   hipStream_t st, int force_tile) {
     const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
     if constexpr (sizeof(T) == 2) {
-        // bf16 throughput path: ping-pong kernel (byte offsets are 32-bit: operands must stay below 4 GiB)
-        if (big && !(e.dbg & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 32) && (size_t)N * ldw * 2 < ((size_t)1 << 32))
+        // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
+        // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
+        if (big && !(VV_DBG(e) & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
-    if (big && (e.dbg & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    if (big && (VV_DBG(e) & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
@@ -671,10 +700,12 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos;
-    {   // timing-only ablation bits for tools/gemm_bench.py; read once per process, 0 in production
+#ifdef VV_GEMM_ABLATE
+    {   // ablation build only (never the shipped library): bits from the environment, read once per process
         static const int dbg_env = [] { const char* d = getenv("VV_GEMM_DBG"); return d ? atoi(d) : 0; }();
         e.dbg = dbg_env;
     }
+#endif
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {
         *err = "gemm: rope epilogue needs the four tables and rope_dim % 64 == 0"; return -22;
     }

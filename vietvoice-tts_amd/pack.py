@@ -43,24 +43,27 @@ def _pad1(t: torch.Tensor, n: int) -> torch.Tensor:
 
 
 def rope_tables(spec: ModelSpec, max_pos: int = MAX_POS):
-    inv = 1.0 / (spec.rope_theta ** (torch.arange(0, spec.head_dim, 2, dtype=torch.float32) / spec.head_dim))
-    ang = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv).repeat_interleave(2, dim=-1)
+    """Tables are DEFINED in float64 (angle = pos * theta^(-2i/hd), then cos/sin, then one rounding to fp32) so that any
+    implementation reproduces them to an fp32 ulp; an fp32 angle would carry ~1.5e-4 rad of rounding at position 4096."""
+    inv = 1.0 / (spec.rope_theta ** (torch.arange(0, spec.head_dim, 2, dtype=torch.float64) / spec.head_dim))
+    ang = torch.outer(torch.arange(max_pos, dtype=torch.float64), inv).repeat_interleave(2, dim=-1)
     scale = spec.head_dim ** -0.5
-    return (ang.cos() * scale).contiguous(), (ang.sin() * scale).contiguous(), ang.cos().contiguous(), ang.sin().contiguous()
+    f = lambda t: t.to(torch.float32).contiguous()
+    return f(ang.cos() * scale), f(ang.sin() * scale), f(ang.cos()), f(ang.sin())
 
 
 def text_pos_table(spec: ModelSpec, max_pos: int = MAX_POS) -> torch.Tensor:
     d = spec.text_dim
-    freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32)[: d // 2] / d))
-    ang = torch.outer(torch.arange(max_pos, dtype=torch.float32), freqs)
-    return torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+    freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+    ang = torch.outer(torch.arange(max_pos, dtype=torch.float64), freqs)
+    return torch.cat([ang.cos(), ang.sin()], dim=-1).to(torch.float32).contiguous()
 
 
 def time_sinus_table(spec: ModelSpec, t_grid: torch.Tensor) -> torch.Tensor:
     half = spec.time_freq_dim // 2
-    emb = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
-    arg = 1000.0 * t_grid.to(torch.float32).unsqueeze(1) * emb.unsqueeze(0)
-    return torch.cat([arg.sin(), arg.cos()], dim=-1).contiguous()
+    emb = torch.exp(torch.arange(half, dtype=torch.float64) * -(math.log(10000.0) / (half - 1)))
+    arg = 1000.0 * t_grid.to(torch.float32).to(torch.float64).unsqueeze(1) * emb.unsqueeze(0)
+    return torch.cat([arg.sin(), arg.cos()], dim=-1).to(torch.float32).contiguous()
 
 
 Entry = Tuple[str, torch.dtype, Tuple[int, ...], Callable[[Dict[str, torch.Tensor]], torch.Tensor]]

@@ -96,6 +96,10 @@ EXPORTS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vv_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vv_decode_ws_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "vv_decode_into": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "vv_ws_generation": (C.c_uint64, [C.c_void_p]),
     "vv_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vv_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_gemm": (C.c_int, [C.c_void_p, C.POINTER(vv_gemm_args), C.c_void_p]),
@@ -369,9 +373,10 @@ class HipSynth:
 
 
 class GraphedDecode:
-    """hipGraph replay of ``HipSynth.decode`` at a fixed (B, N, t_gen_max).  Static input buffers are
-    owned here; ``__call__`` copies the state in and replays.  The workspace is sized by a warm-up call
-    before capture (no allocation may happen inside a captured region)."""
+    """hipGraph replay of the decode stage at a fixed (B, N, t_gen_max).  Static input/output buffers AND the
+    stage's whole workspace are owned here (``vv_decode_into``): the captured launches point only into memory
+    that lives as long as this object, so later calls that grow the context arena cannot invalidate the graph.
+    ``__call__`` copies the state in and replays."""
 
     def __init__(self, eng: HipSynth, B: int, N: int, t_gen_max: int):
         self.eng, self.B, self.N, self.t_gen_max = eng, B, N, t_gen_max
@@ -381,7 +386,10 @@ class GraphedDecode:
         self.seq_len = torch.full((B,), N, dtype=torch.int32, device=dev)
         self.pcm = torch.zeros((B, t_gen_max * s.hop_length), dtype=torch.int16, device=dev)
         self.pcm_len = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self._launch()                                   # warm-up: sizes the workspace, sets kernel attributes
+        nb = C.c_uint64()
+        eng._check(eng.lib.vv_decode_ws_bytes(eng.ctx, B, t_gen_max, C.byref(nb)))
+        self.ws = torch.empty((int(nb.value),), dtype=torch.uint8, device=dev)       # torch allocations are 512-byte aligned
+        self._launch()                                   # warm-up: sets kernel attributes before capture
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -390,12 +398,14 @@ class GraphedDecode:
     def _launch(self):
         e = self.eng
         with e._lock, torch.cuda.device(e.device):
-            e._check(e.lib.vv_decode(e.ctx, self.B, self.N, self.x.data_ptr(), self.ref_len.data_ptr(), self.seq_len.data_ptr(),
-                                     self.t_gen_max, self.pcm.data_ptr(), self.pcm.shape[1], self.pcm_len.data_ptr(), None, e._stream()))
+            e._check(e.lib.vv_decode_into(e.ctx, self.B, self.N, self.x.data_ptr(), self.ref_len.data_ptr(), self.seq_len.data_ptr(),
+                                          self.t_gen_max, self.pcm.data_ptr(), self.pcm.shape[1], self.pcm_len.data_ptr(), None,
+                                          self.ws.data_ptr(), self.ws.numel(), e._stream()))
 
     def __call__(self, x: torch.Tensor, ref_len: torch.Tensor, seq_len: torch.Tensor):
-        self.x.copy_(x)
-        self.ref_len.copy_(ref_len)
-        self.seq_len.copy_(seq_len)
-        self.graph.replay()
+        with self.eng._lock:                             # one stream of work per context, replay included
+            self.x.copy_(x)
+            self.ref_len.copy_(ref_len)
+            self.seq_len.copy_(seq_len)
+            self.graph.replay()
         return self.pcm, self.pcm_len
