@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds/sec (24 kHz) at batch 32, 256-token utterances, per BASELINE.json.
 
-One "step" = one pass of the whole synthesis hot path over one batch of synthetic utterances that are
-already resident in HBM: preprocess (mel + text conditioning) -> 31 flow-matching Euler steps x 2 CFG
-branches through the 22-block DiT -> vocoder -> int16 PCM in HBM.  Work per utterance follows
+One "step" = one pass of the whole synthesis hot path over one batch of synthetic utterances, timed as
+SURVEY.md 8(d) defines the metric: tokenised inputs resident on the HOST (int16 reference clips, int32 ids,
+fp32 noise in pinned memory) -> H2D -> preprocess (mel + text conditioning) -> 31 flow-matching Euler steps
+x 2 CFG branches through the 22-block DiT -> vocoder -> int16 PCM copied back to pinned HOST memory
+(~46 MB over PCIe per step, ~0.1 % of the step; `--resident` keeps inputs/outputs in HBM instead).
+Work per utterance follows
 SURVEY.md 8(d): T = 256 ids (96 reference + 160 target), 6.0 s reference clip (144,000 samples ->
 563 frames), 1037 generated frames, N = 1600 frames, 265,472 output samples = 11.061 s of audio.
 
@@ -61,6 +64,8 @@ def make_inputs(spec: ModelSpec, B: int, rank: int, device):
     d = dict(audio=audio.to(device), audio_len=torch.full((B,), REF_SAMPLES, dtype=torch.int32, device=device),
              ids=ids.to(device), text_len=torch.full((B,), TEXT_TOKENS, dtype=torch.int32, device=device),
              seq_len=torch.full((B,), N, dtype=torch.int32, device=device), noise=noise.to(device))
+    if torch.device(device).type == "cuda":          # host-side originals (pinned) for the H2D leg of the timed step
+        d["host"] = {k: t.pin_memory() for k, t in (("audio", audio), ("ids", ids), ("noise", noise))}
     return d, N
 
 
@@ -93,6 +98,7 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
         noise = torch.randn(B, N, spec.n_mel, generator=g, dtype=torch.float32)
         d = dict(audio=audio.to(device), audio_len=samples[units].to(torch.int32).to(device), ids=ids.to(device),
                  text_len=toks[units].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
+        d["host"] = {k: t.pin_memory() for k, t in (("audio", audio), ("ids", ids), ("noise", noise))}
         d["gen_frames"] = [int(gen_frames[u]) for u in units]
         batches.append((d, N, int(gen_frames[units].max())))
     audio_s = float(gen_frames[mine].sum()) * spec.hop_length / spec.sample_rate
@@ -176,6 +182,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--nfe", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resident", action="store_true", help="keep inputs and PCM in HBM (no PCIe leg in the timed step)")
     ap.add_argument("--spec", default="full", choices=["full", "small", "tiny"])
     ap.add_argument("--workload", default="batch32", choices=["batch32", "mixed256", "longform"],
                     help="batch32 = the headline metric (BASELINE configs[2]); mixed256 = configs[3] (32 ragged units per GPU); "
@@ -222,10 +229,24 @@ def main():
         d, N = make_inputs(spec, a.batch, rank, device)
         batches, audio_s_rank, nb, fill = [(d, N, GEN_FRAMES)], a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch, 1.0
 
-    def step():
-        outs = [eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], N, d["noise"], t_gen,
-                                     gen_frames=d.get("gen_frames"))
-                for d, N, t_gen in batches]
+    pcm_host = [None] * len(batches)          # pinned landing buffers for the D2H leg, allocated by the first (warm-up) step
+
+    def step(pcie=not a.resident):
+        """host inputs -> H2D -> three stages -> D2H of the PCM; returns when the PCM is on the host."""
+        outs = []
+        for i, (d, N, t_gen) in enumerate(batches):
+            if pcie:
+                audio, ids, noise = (d["host"][k].to(device, non_blocking=True) for k in ("audio", "ids", "noise"))
+            else:
+                audio, ids, noise = d["audio"], d["ids"], d["noise"]
+            o = eng.synthesize_batch(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, noise, t_gen, gen_frames=d.get("gen_frames"))
+            if pcie:
+                if pcm_host[i] is None:
+                    pcm_host[i] = (torch.empty(o[1].shape, dtype=o[1].dtype).pin_memory(), torch.empty(o[2].shape, dtype=o[2].dtype).pin_memory())
+                pcm_host[i][0].copy_(o[1], non_blocking=True)
+                pcm_host[i][1].copy_(o[2], non_blocking=True)
+            outs.append(o)
+        torch.cuda.synchronize()               # the step ends when the int16 PCM is on the host
         return outs
 
     for _ in range(a.warmup):
@@ -233,9 +254,12 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        ts = time.perf_counter()
         out = step()
+        step_s.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -245,6 +269,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert abs(sum(float(o[2].sum().item()) for o in out) / spec.sample_rate - audio_s_rank) < 1e-3
+    if not a.resident:                                    # what landed on the host is the PCM the device produced
+        assert all(torch.equal(h[1], o[2].cpu()) and int(h[0].abs().max()) > 0 for h, o in zip(pcm_host, out))
     if dist is not None:                                  # total audio over all ranks (ragged shards differ)
         ta = torch.tensor([audio_s_rank], dtype=torch.float64, device=device)
         dist.all_reduce(ta, op=dist.ReduceOp.SUM)
@@ -266,13 +292,19 @@ def main():
     gm = prof["gemm"]
     peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-    traffic, traffic_src = None, None                 # HBM-side bytes per launch from the committed PMC passes (bench.py cannot run rocprofv3 itself)
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "gemm_pmc_traffic.json")
-    if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
-        with open(tf) as fh:
-            tj = json.load(fh)
-        traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01/gemm_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
-    roofline = {"bound": "mfma", "kernel": "gemm_kernel (K6, %s MFMA)" % a.dtype, "achieved": round(ach, 2), "peak": peak,
+    # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so the figure comes from the committed
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command (tools/pmc_traffic.py -> profiles/<round>/bench_pmc_traffic.json)
+    traffic, traffic_src = None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for rel in ("profiles/r02/bench_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
+        tf = os.path.join(here, rel)
+        if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
+            with open(tf) as fh:
+                tj = json.load(fh)
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], rel + " (" + tj.get("how_short", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction") + ")"
+            break
+    kname = "gemm_pp_kernel (K6, persistent 256x256x64 ping-pong, bf16 MFMA 16x16x32)" if a.dtype == "bf16" else "gemm_kernel (K6, f32 MFMA 32x32x2)"
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4)}
     def _rf(name, bound, peak):
@@ -297,9 +329,15 @@ def main():
     res = {
         "metric": "audio-seconds/sec (24 kHz) at batch 32, 256-token utterances; RTF",
         "value": round(total_audio / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 2), "median_ms_per_step": round(sorted(step_s)[len(step_s) // 2] * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic (seeded utterances and random-init weights; no checkpoint offline)",
         "rtf": round(elapsed / total_audio, 6),
+        "timed_region": ("inputs and PCM resident in HBM (--resident)" if a.resident else
+                         "host (pinned) int16 clips / ids / noise -> H2D -> preprocess + Euler steps + vocoder -> int16 PCM D2H to pinned host memory (SURVEY 8d)"),
+        "hbm_target_note": "north_star's '>= 40 % of HBM roofline on the vocoder kernel' applies to the memory-bound vocoder kernels only (K13 conv_post+tanh+int16, "
+                           "K10 frame slice): in fp32 every MRF / upsample conv has arithmetic intensity 32-450 flop/B, above the f32 ridge (~20), and is reported "
+                           "against the 157.3 TFLOP/s f32 MFMA roof instead (SURVEY 7 / 8d)",
         "config": {"workload": (f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
                                 if a.workload == "batch32" else
                                 f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips) in "

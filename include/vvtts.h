@@ -144,7 +144,8 @@ typedef struct vv_attn_args {
     const int32_t* kv_len;
     const int32_t* row_start;  /* optional [n_seq]: packed ragged rows -- sequence s owns rows [row_start[s], +kv_len[s]);
                                   default s * seq_n (padded layout, rows beyond kv_len are computed and ignored) */
-    int32_t total_rows;        /* rows in the qkv / out buffers (bounds the K/V buffer resource); 0 = n_seq * seq_n */
+    int32_t total_rows;        /* rows in the qkv / out buffers (bounds the K/V buffer resource; reads past it return zero).
+                                  Required (> 0) with row_start; 0 = n_seq * seq_n in the padded layout */
 } vv_attn_args;
 int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
 

@@ -71,19 +71,22 @@ def oracle_hann(win_length: int) -> torch.Tensor:
 
 
 class Oracle:
-    def __init__(self, spec, weights: Dict[str, torch.Tensor], nfe_step: int = 32):
+    def __init__(self, spec, weights: Dict[str, torch.Tensor], nfe_step: int = 32, dtype: torch.dtype = torch.float32):
+        """dtype = torch.float64 runs the SAME fp32 weights, tables and inputs through float64 arithmetic: the yardstick for what
+        fp32 rounding alone costs at a given size (tests/test_fullsize_gpu.py derives its tolerance from it)."""
         self.spec = spec
-        self.w = {k: v.to(torch.float32) for k, v in weights.items()}
+        self.dt = dtype
+        self.w = {k: v.to(torch.float32).to(dtype) for k, v in weights.items()}
         self.nfe_step = nfe_step
         self.t_grid, self.dt_grid = oracle_time_grid(nfe_step, spec.sway_coef)
-        self.fb = oracle_mel_filterbank(spec.sample_rate, spec.n_fft, spec.n_mel)
-        self.window = oracle_hann(spec.win_length)
+        self.fb = oracle_mel_filterbank(spec.sample_rate, spec.n_fft, spec.n_mel).to(dtype)
+        self.window = oracle_hann(spec.win_length).to(dtype)
 
     # ------------------------------------------------------------------ preprocess
     def mel(self, audio_i16: torch.Tensor) -> torch.Tensor:
         """int16 (S,) -> log-mel (S//hop+1, n_mel).  Frame count follows tts_engine.py:55."""
         s = self.spec
-        x = audio_i16.to(torch.float32) / 32768.0
+        x = audio_i16.to(self.dt) / 32768.0
         st = torch.stft(x, s.n_fft, hop_length=s.hop_length, win_length=s.win_length, window=self.window,
                         center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
         mag = st.abs()                                  # (n_fft/2+1, frames)
@@ -94,7 +97,7 @@ class Oracle:
         """[cos | sin] halves of pos * 10000^(-2i/d), float64 then fp32."""
         d = self.spec.text_dim
         ang = np.arange(n, dtype=np.float64)[:, None] * np.power(10000.0, -np.arange(0, d, 2, dtype=np.float64) / d)[None, :]
-        return torch.from_numpy(np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32))
+        return torch.from_numpy(np.concatenate([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)).to(self.dt)
 
     def grn(self, x: torch.Tensor, gamma, beta) -> torch.Tensor:
         gx = torch.norm(x, p=2, dim=0, keepdim=True)            # over the sequence, per channel
@@ -130,7 +133,7 @@ class Oracle:
         ang = np.arange(n, dtype=np.float64)[:, None] * np.power(float(s.rope_theta), -np.arange(0, hd, 2, dtype=np.float64) / hd)[None, :]
         ang = np.repeat(ang, 2, axis=1)
         scale = float(hd) ** -0.5
-        f = lambda a: torch.from_numpy(a.astype(np.float32))
+        f = lambda a: torch.from_numpy(a.astype(np.float32)).to(self.dt)
         return f(np.cos(ang) * scale), f(np.sin(ang) * scale), f(np.cos(ang)), f(np.sin(ang))
 
     def preprocess(self, audio_i16: torch.Tensor, text_ids: torch.Tensor, max_duration: int,
@@ -147,7 +150,7 @@ class Oracle:
         te_drop = self.text_embed(text_ids, n, drop=True)
         cq, sq, ck, sk = self.rope_tables(n)
         return {
-            "noise": noise.to(torch.float32).clone(),
+            "noise": noise.to(torch.float32).to(self.dt).clone(),
             "rope_cos_q": cq, "rope_sin_q": sq, "rope_cos_k": ck, "rope_sin_k": sk,
             "cat_mel_text": torch.cat([cond, te], dim=-1),
             "cat_mel_text_drop": torch.cat([torch.zeros_like(cond), te_drop], dim=-1),
@@ -159,7 +162,7 @@ class Oracle:
         s, w = self.spec, self.w
         half = s.time_freq_dim // 2
         arg = 1000.0 * float(self.t_grid[step]) * np.exp(-np.arange(half, dtype=np.float64) * (math.log(10000.0) / (half - 1)))
-        emb = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32))       # [sin | cos], float64 then fp32
+        emb = torch.from_numpy(np.concatenate([np.sin(arg), np.cos(arg)]).astype(np.float32)).to(self.dt)      # [sin | cos], float64 then fp32
         h = F.silu(F.linear(emb, w["time.mlp1.weight"], w["time.mlp1.bias"]))
         return F.linear(h, w["time.mlp2.weight"], w["time.mlp2.bias"])
 
@@ -221,7 +224,7 @@ class Oracle:
         pc = self.dit_forward(x, pre["cat_mel_text"], ropes, step)
         pu = self.dit_forward(x, pre["cat_mel_text_drop"], ropes, step)
         pred = pc + (pc - pu) * self.spec.cfg_strength
-        return x + pred * self.dt_grid[step]
+        return x + pred * float(self.dt_grid[step])
 
     # ------------------------------------------------------------------ decode
     def vocoder(self, mel: torch.Tensor) -> torch.Tensor:

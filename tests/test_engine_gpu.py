@@ -183,3 +183,28 @@ def test_bench_json_contract():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["cores"] >= 1
+    assert d["median_ms_per_step"] > 0 and "H2D" in d["timed_region"] and "D2H" in d["timed_region"] and "hbm_target_note" in d
+
+
+def test_bench_two_rank_branch_over_gloo():
+    """The N > 1 branch of bench.py (rendezvous, rank-0 weight pack + broadcast, barriers, MAX-over-ranks time, SUM of audio, one
+    JSON line on rank 0) kept alive without multi-GPU hardware: two ranks under torch.distributed.run share cuda:0 with
+    VV_BENCH_DIST_BACKEND=gloo.  Started as a FRESH child process tree (this test process never execs; the children initialise
+    the GPU themselves).  RCCL over xGMI itself stays unmeasured until the driver's 8-GPU run."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VV_BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny", "--steps", "1", "--warmup", "0", "--batch", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "dp2" in d["config"]["parallelism"]
+    assert d["weight_pack_and_broadcast_ms"] > 0 and "cpu_baseline" not in d         # cpu_baseline is an N = 1 leg
+    per_rank_audio = 4 * 1037 * 256 / 24000.0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank_audio) < 0.02 * per_rank_audio      # value = SUM of audio over ranks / MAX time

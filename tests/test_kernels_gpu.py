@@ -184,6 +184,8 @@ def test_packed_rows_rope_attention_posconv(hip_tiny, dtype, tiny_setup):
     dq = qkv.to(gu.DEV)
     a.qkv, a.ld_qkv, a.out, a.ld_out = dq.data_ptr(), 3 * D, out.data_ptr(), D
     a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len, a.row_start = len(lens), N, heads, D, sl.data_ptr(), rs.data_ptr()
+    assert eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()) != 0            # packed rows without the buffer's row count are refused
+    a.total_rows = R                          # the last tile of the last sequence reads past row R: the resource bound makes that zeros
     gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
     torch.cuda.synchronize()
     f = qkv.float().reshape(R, 3, heads, 64)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""A/B libraries for one kernel file: tools/build_variants.py <source stem> name=-DFLAG[,-DFLAG2] ...
+Each variant recompiles only csrc/<stem>.hip with the extra flags and links it with the objects of the shipped build
+into vietvoice-tts_amd/build/variants/libvvtts_<name>.so (they travel to the GPU box with the snapshot; git-ignored)."""
+import importlib.util, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("vv_build_ext", os.path.join(ROOT, "vietvoice-tts_amd", "build_ext.py"))
+be = importlib.util.module_from_spec(spec); spec.loader.exec_module(be)
+be.build()
+stem = sys.argv[1]
+out_dir = os.path.join(be.HERE, "build", "variants")
+os.makedirs(out_dir, exist_ok=True)
+for item in sys.argv[2:]:
+    name, _, flags = item.partition("=")
+    obj = os.path.join(out_dir, f"{stem}_{name}.o")
+    cmd = [be._hipcc()] + be.FLAGS + [f for f in flags.split(",") if f] + ["-c", os.path.join(be.CSRC, stem + ".hip"), "-o", obj]
+    subprocess.run(cmd, check=True)
+    objs = [obj if s == stem else os.path.join(be.OBJ, s + ".o") for s in be.SOURCES]
+    lib = os.path.join(out_dir, f"libvvtts_{name}.so")
+    subprocess.run([be._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    print(lib)

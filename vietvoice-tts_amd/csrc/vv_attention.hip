@@ -46,7 +46,12 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------ bf16
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
+#ifdef VV_ATTN_LB4
+#define VV_ATTN_MIN_WAVES 4
+#else
+#define VV_ATTN_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
                                                            const int* __restrict__ row_start, int total_rows) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
@@ -132,6 +137,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+#ifdef VV_ATTN_TAILSKIP
+        if (q0 >= q_lim) continue;           // a wave whose 32 queries all lie past the sequence only stages its K/V pieces
+#endif
         const char* sK = smem + (kt & 1) * 16384;
         const char* sV = sK + 8192;
 
@@ -181,6 +189,101 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
         // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
         // which path ran.
+#ifdef VV_ATTN_V2
+        // ---- interior tiles (not the first, not the masked last one): the 64 keys are two 32-key halves of the online softmax,
+        // software-pipelined INSIDE the wave: the exponentials of half 0 are issued between the QK^T MFMAs of half 1, the
+        // exponentials of half 1 between the PV MFMAs of half 0 (a wave issues in order: without the interleave its matrix pipe
+        // idles through every softmax block and its VALU through every MFMA block).  Same registers as the whole-tile form
+        // (s0/s1 are s[0]/s[1]); each half is its own speculative sub-tile: half 0 failing its check falls back to the whole-tile
+        // careful path below (nothing is committed yet), half 1 failing redoes half 1 alone against the state that already
+        // holds half 0.
+        bool fast_done = false;
+        if (kt != 0 && kbase + 64 <= kv_len) {
+            auto qk_half = [&](int kb, f32x16 c) {
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], c, 0, 0, 0);
+                }
+                return c;
+            };
+            auto exp_half = [&](f32x16& v) -> float {
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = fast_exp2(v[r]);
+                    ps[r & 3] += pv;
+                    v[r] = pv;
+                }
+                return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            };
+            auto pv_half = [&](int kb, const f32x16& pr) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const f32x8 pv = {pr[8 * st + 0], pr[8 * st + 1], pr[8 * st + 2], pr[8 * st + 3],
+                                      pr[8 * st + 4], pr[8 * st + 5], pr[8 * st + 6], pr[8 * st + 7]};
+                    const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
+                        const char* a1 = a0 + 8 * 128;
+                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
+                        const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+            };
+            const f32x16 sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
+            s[0] = qk_half(0, sx);
+            s[1] = qk_half(1, sx);
+            const float p0 = exp_half(s[0]);
+            // program order of this region: ext + 4 MFMAs of half 0, then each MFMA of half 1 followed by 4 exp + 4 add of half 0
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            if (!__any(!(p0 <= RESCALE_SUM))) {
+                l_run += p0;
+                pv_half(0, s[0]);
+                float p1 = exp_half(s[1]);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);          // the 8 v_cvt_pk of half 0 first
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 4, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
+                }
+                if (__any(!(p1 <= RESCALE_SUM))) {                           // rare: half 1 alone, the careful way
+                    s[1] = qk_half(1, __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0));   // sx is not kept live for this
+                    float mx = s[1][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+                    mx = half_max(mx);
+                    const float m_new = bf16_round(m_eff + fmaxf(mx, 0.f));
+                    const float d = m_new - m_eff;
+                    const float alpha = fast_exp2(-d);
+                    l_run *= alpha;                                          // l and O already hold half 0 at the old reference
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[1][r] -= d;
+                    m_eff = m_new;
+                    q_ext = make_q_ext(-m_new, h);
+                    p1 = exp_half(s[1]);
+                }
+                l_run += p1;
+                pv_half(1, s[1]);
+                fast_done = true;
+            }
+        }
+        if (fast_done) continue;
+#endif
         float psum = 0.f;
         bool redo = kt == 0;
         if (!redo) {
@@ -396,6 +499,9 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     }
     if (a->ld_qkv < 3 * a->dim || a->ld_out < a->dim) { *err = "attention: leading dimensions too small"; return -22; }
     if (a->row_start && !a->kv_len) { *err = "attention: packed rows need kv_len"; return -22; }
+    // the last tile of the last packed sequence reads past its rows: total_rows is what bounds the K/V buffer resource there
+    // (out-of-range rows read as zero), so with packed rows it cannot be defaulted
+    if (a->row_start && a->total_rows <= 0) { *err = "attention: packed rows need total_rows (rows in the qkv buffer)"; return -22; }
     const int total_rows = a->total_rows > 0 ? a->total_rows : a->n_seq * a->seq_n;
     if (a->dtype == VV_BF16 && (size_t)total_rows * a->ld_qkv * 2 >= ((size_t)1 << 31)) { *err = "attention: qkv buffer must stay below 2 GiB"; return -22; }
     if (a->row_start == nullptr && total_rows < a->n_seq * a->seq_n) { *err = "attention: total_rows smaller than n_seq * seq_n"; return -22; }
