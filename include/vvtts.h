@@ -106,6 +106,10 @@ int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref
                    void* stream);
 uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
 
+/* Context switches (explicit API, never the environment).  "fuse_mrf" (default 1): run the MRF resblock pairs of the C <= 64
+ * vocoder stages through vv_mrf_resblock's fused kernel; 0 = two vv_conv1d launches per pair (bit-identical results). */
+int vv_set_option(vv_ctx* ctx, const char* name, int value);
+
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
 #define VV_PROF_GEMM 0
 #define VV_PROF_ATTN 1
@@ -188,6 +192,21 @@ typedef struct vv_conv_args {
     const int32_t* len_in;    /* optional per-item valid input length */
 } vv_conv_args;
 int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
+
+/* K12, one (kernel, dilation) pair of an MRF resblock fused through LDS (SURVEY 8(a) K12 / 8(b) vv_mrf_resblock):
+ *   out = [accumulate ? out : 0] + out_scale * ( conv2(lrelu(conv1(lrelu(y)))) + y ),  conv1 dilated, conv2 undilated, C -> C.
+ * Fused form for C = 32 / 64 (the intermediate tile stays in the CU); bit-identical to vv_conv1d(conv1) + vv_conv1d(conv2, resid = y).
+ * replaces two nodes of decode.onnx's HiFi-GAN resblock (reference core/tts_engine.py:176-187 runs the graph; no source). */
+typedef struct vv_mrf_args {
+    const float* y;           /* [B][C][T] resblock input (also the residual) */
+    const float *W1, *b1;     /* conv1: [C_pad8][KW][64], [C] */
+    const float *W2, *b2;     /* conv2 */
+    float* out;               /* [B][C][T], must not alias y */
+    int32_t B, C, T, KW, dil, rows_pad, accumulate;
+    float slope, out_scale;
+    const int32_t* len_in;    /* optional per-item valid length */
+} vv_mrf_args;
+int vv_mrf_resblock(vv_ctx* ctx, const vv_mrf_args* args, void* stream);
 
 int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32,
                  int B, int C, int T, int KW, float pre_slope, const int32_t* len_in, void* stream);

@@ -155,6 +155,18 @@ def test_fp32_vocoder_alone_on_the_oracle_state(full_case):
     diff = (pcm[0, :n].cpu().int() - c["pcm"].int()).abs()
     print(f"\n[full vocoder] waveform max abs err {e_w:.2e}; PCM max diff {int(diff.max())} LSB on {int((diff > 0).sum())} of {n} samples")
     assert int(pcm_len[0]) == n and e_w < 1e-5 and int(diff.max()) <= 1
+    # K12: the fused MRF pairs (stages with C = 64 and 32, 18 of the 36 pairs) against two launches per pair: bit-identical
+    eng.set_option("fuse_mrf", 0)
+    pcm_u, len_u, wave_u = eng.decode(x, pre, bench.GEN_FRAMES, want_wave=True)
+    torch.cuda.synchronize()
+    assert torch.equal(pcm_u, pcm) and torch.equal(wave_u, wave) and torch.equal(len_u, pcm_len)
+    eng.prof_enable(True)
+    for fuse in (1, 0):
+        eng.set_option("fuse_mrf", fuse)
+        eng.decode(x, pre, bench.GEN_FRAMES)
+        pr = eng.prof_collect()["voc_conv"]
+        print(f"[full vocoder] fuse_mrf={fuse}: {pr['launches']} conv launches, {pr['ms']:.3f} ms (B = 1)")
+    eng.prof_enable(False)
     eng.close()
 
 

@@ -451,6 +451,47 @@ def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T):
     assert gu.rel_err(got2, ref2) < TOL_F32
 
 
+@pytest.mark.parametrize("KW,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5)])
+@pytest.mark.parametrize("C_,T", [(32, 1000), (64, 517), (64, 116), (32, 131)])
+def test_mrf_resblock_fused_is_bit_identical_to_two_convs(hip_tiny, KW, dil, C_, T):
+    """K12 (SURVEY 8a / 8b vv_mrf_resblock): conv1 -> LeakyReLU -> conv2 (+ residual, MRF scale, accumulate) through LDS in one
+    launch.  Same contraction order and epilogue arithmetic as the per-conv kernel, so the result equals vv_conv1d(conv1) +
+    vv_conv1d(conv2, resid = y) BIT FOR BIT (ragged lengths, tile seams and the accumulate form included), and matches torch
+    within the fp32 kernel tolerance."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(KW * 1000 + dil * 10 + C_ + T)
+    B = 3
+    lens = [T, max(1, T // 3), max(1, T - 7)]
+    y = torch.randn(B, C_, T, generator=g)
+    w1 = torch.randn(C_, C_, KW, generator=g) * 1.4 / math.sqrt(C_ * KW)
+    w2 = torch.randn(C_, C_, KW, generator=g) * 0.45 / math.sqrt(C_ * KW)
+    b1, b2 = torch.randn(C_, generator=g) * 0.1, torch.randn(C_, generator=g) * 0.1
+    prev = torch.randn(B, C_, T, generator=g)
+    p1, p2 = _pack_conv(w1), _pack_conv(w2)
+    for accumulate, scale in ((0, 1.0), (1, 1.0 / 3.0)):
+        t1 = _run_conv(eng, rt, gu, y, p1, b1, C_, T, KW, dil, 0, pre_slope=0.1, lens=lens)
+        two = _run_conv(eng, rt, gu, t1.cpu(), p2, b2, C_, T, KW, 1, 0, resid=y, pre_slope=0.1, scale=scale, accumulate=accumulate,
+                        out0=prev if accumulate else None, lens=lens)
+        out = (prev.clone() if accumulate else torch.zeros(B, C_, T)).to(gu.DEV)
+        dev = [t.to(gu.DEV) for t in (y, p1, b1, p2, b2)]
+        dl = torch.tensor(lens, dtype=torch.int32, device=gu.DEV)
+        a = rt.vv_mrf_args()
+        a.y, a.W1, a.b1, a.W2, a.b2, a.out = [t.data_ptr() for t in dev] + [out.data_ptr()]
+        a.B, a.C, a.T, a.KW, a.dil, a.rows_pad, a.accumulate, a.slope, a.out_scale, a.len_in = B, C_, T, KW, dil, 64, accumulate, 0.1, scale, dl.data_ptr()
+        gu.check(eng, eng.lib.vv_mrf_resblock(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, two), float((out - two).abs().max())
+        for i, L in enumerate(lens):
+            yi = y[i:i + 1, :, :L]
+            ref = F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(yi, 0.1), w1, b1, dilation=dil, padding=dil * (KW - 1) // 2), 0.1), w2, b2,
+                           padding=(KW - 1) // 2) + yi
+            ref = ref * scale + (prev[i:i + 1, :, :L] if accumulate else 0)
+            assert gu.rel_err(out[i:i + 1, :, :L], ref) < TOL_F32
+    a.C = 128
+    assert eng.lib.vv_mrf_resblock(eng.ctx, C.byref(a), gu.stream()) != 0            # wider stages are refused (intermediate does not fit)
+
+
 def test_conv1d_length_mask(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]

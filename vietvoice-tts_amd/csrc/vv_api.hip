@@ -43,6 +43,7 @@ struct vv_ctx {
     size_t ar_cap = 0, ar_off = 0;
     uint64_t ws_generation = 0;         // bumped whenever ws is reallocated
     int* d_mult = nullptr;              // decode length multipliers
+    bool fuse_mrf = true;               // K12: MRF pairs of the C <= 64 stages run fused through LDS (vv_set_option "fuse_mrf")
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -586,10 +587,22 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
             const float* y = up_out;
             for (int b = 0; b < g.voc_n_dil; ++b) {
                 const std::string q = "voc.res." + std::to_string(s) + "." + std::to_string(a) + "." + std::to_string(b);
-                if (int r = conv(y, q + ".conv1", t1, nullptr, C, C, T, T, g.voc_res_kernels[a], g.voc_res_dilations[b], 0, g.voc_lrelu, 1.0f, 0, len_s)) return r;
                 const bool last = b == g.voc_n_dil - 1;
                 float* dst = last ? acc : ((y == ya) ? yb : ya);
-                if (int r = conv(t1, q + ".conv2", dst, y, C, C, T, T, g.voc_res_kernels[a], 1, 0, g.voc_lrelu, last ? inv : 1.0f, last && a > 0, len_s)) return r;
+                const int kw = g.voc_res_kernels[a], dil = g.voc_res_dilations[b];
+                if (c->fuse_mrf && (C == 32 || C == 64) && (kw == 3 || kw == 7 || kw == 11)) {
+                    // K12 fused through LDS: the intermediate of the pair never reaches HBM (bit-identical to the two launches below)
+                    vv_mrf_args m{};
+                    m.y = y; m.W1 = c->Wf(q + ".conv1.weight"); m.b1 = c->Wf(q + ".conv1.bias"); m.W2 = c->Wf(q + ".conv2.weight"); m.b2 = c->Wf(q + ".conv2.bias");
+                    m.out = dst; m.B = B; m.C = C; m.T = T; m.KW = kw; m.dil = dil; m.rows_pad = 64; m.accumulate = last && a > 0;
+                    m.slope = g.voc_lrelu; m.out_scale = last ? inv : 1.0f; m.len_in = len_s;
+                    Prof p(c, VV_PROF_VOC_CONV, 2.0 * 2.0 * B * (double)T * C * C * kw, 4.0 * B * (double)C * T * (2 + (m.accumulate ? 1 : 0)), st);
+                    const char* em = "";
+                    if (int r = vvk_mrf_pair(&m, st, &em)) return c->fail(r, "%s (%s)", em, q.c_str());
+                } else {
+                    if (int r = conv(y, q + ".conv1", t1, nullptr, C, C, T, T, kw, dil, 0, g.voc_lrelu, 1.0f, 0, len_s)) return r;
+                    if (int r = conv(t1, q + ".conv2", dst, y, C, C, T, T, kw, 1, 0, g.voc_lrelu, last ? inv : 1.0f, last && a > 0, len_s)) return r;
+                }
                 y = dst;
             }
         }
@@ -606,6 +619,12 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
                               lens + (size_t)nu * B, st, &m__));
     }
     return 0;
+}
+
+int vv_set_option(vv_ctx* c, const char* name, int value) {
+    if (!c || !name) return -22;
+    if (!strcmp(name, "fuse_mrf")) { c->fuse_mrf = value != 0; return 0; }
+    return c->fail(-22, "vv_set_option: unknown option '%s'", name);
 }
 
 int vv_decode(vv_ctx* c, int B, int N, const float* x, const int32_t* ref_len, const int32_t* seq_len, int t_gen_max, int16_t* pcm,
@@ -665,6 +684,7 @@ int vv_attention(vv_ctx* c, const vv_attn_args* a, void* st) { SINGLE(c, vvk_att
 int vv_layernorm(vv_ctx* c, const vv_ln_args* a, void* st) { SINGLE(c, vvk_ln_mod(a, (hipStream_t)st, &m__)); }
 int vv_posconv(vv_ctx* c, const vv_posconv_args* a, void* st) { SINGLE(c, vvk_posconv(a, (hipStream_t)st, &m__)); }
 int vv_conv1d(vv_ctx* c, const vv_conv_args* a, void* st) { SINGLE(c, vvk_conv(a, (hipStream_t)st, &m__)); }
+int vv_mrf_resblock(vv_ctx* c, const vv_mrf_args* a, void* st) { SINGLE(c, vvk_mrf_pair(a, (hipStream_t)st, &m__)); }
 int vv_conv_post(vv_ctx* c, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T,
                  int KW, float pre_slope, const int32_t* len_in, void* st) {
     SINGLE(c, vvk_conv_post(in, w, bias, pcm, ld_pcm, wave_f32, B, C, T, KW, pre_slope, len_in, (hipStream_t)st, &m__));

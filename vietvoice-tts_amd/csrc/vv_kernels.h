@@ -13,6 +13,7 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err);
 int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err);
 int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err);
 int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err);
+int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err);
 int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T,
                   int KW, float pre_slope, const int* len_in, hipStream_t st, const char** err);
 int vvk_mel_slice(const float* x, int B, int N, int n_mel, const int* ref_len, const int* seq_len, float* out, int T,

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
                                                            int rows_pad, int T_in, int T_out, int Cout, int dil, int up,
                                                            float pre_slope, float out_scale, int accumulate,
                                                            const int* __restrict__ len_in) {
+#pragma clang fp contract(off)      // the epilogue's add / multiply sequence is part of the bit-exact contract with mrf_pair_kernel
     constexpr int VR = RT * 32;
     // halo: conv reads time + kw*dil - left; transposed reads q and q-1.  The staged window starts at the 16-byte aligned
     // time q0 - L4 (L4 = left rounded up to 4), so whole float4s are loaded and the reads shift by L4 - left.
@@ -138,6 +139,156 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
                 outb[o] = v;
             }
         }
+}
+
+// ---- K12 fused: one (kernel, dilation) pair of an MRF resblock in ONE launch,
+//        out = [accumulate ? out : 0] + scale * ( conv2(lrelu(conv1(lrelu(y)))) + y ),
+// conv1 dilated by `dil`, conv2 undilated, both C -> C with C = 32 or 64 (the whole channel dimension is one row tile, so the
+// intermediate never leaves the CU): a workgroup computes a 128-column window of the intermediate t1 into LDS (bias added,
+// second LeakyReLU applied, zero outside [0, len) exactly as the unfused conv2 zero-fills its staged window), then runs conv2
+// straight out of that LDS image and writes the central 128 - E columns (E = KW - 1 rounded up to 4).  Both products keep the
+// unfused kernel's contraction order (channel pairs ascending, taps ascending inside a pair) and epilogue arithmetic, so the
+// result is BIT-IDENTICAL to vv_conv1d(conv1) followed by vv_conv1d(conv2, resid = y).  HBM traffic per pair: y read once
+// (+ halo), out written once -- 2 tensor passes instead of 5.
+constexpr int FT = 128;       // intermediate columns per workgroup (4 waves x one 32-column MFMA tile)
+
+template <int KW, int RT, int VCI>
+__global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restrict__ y, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
+                                                          int C, int rows_pad, int T, int dil, float slope, float out_scale, int accumulate,
+                                                          const int* __restrict__ len_in) {
+#pragma clang fp contract(off)      // same separate add / multiply roundings as conv_mfma_kernel's epilogue
+    constexpr int VR = RT * 32;
+    constexpr int half = (KW - 1) / 2;
+    constexpr int E = (KW - 1 + 3) & ~3;           // columns of the window that are halo only
+    constexpr int VT2 = FT - E;                    // output columns per workgroup
+    constexpr int P = E - half;                    // the t1 window starts P columns before the first output column
+    constexpr int T1P = FT + 4;                    // LDS row pitch of the intermediate
+    const int left1 = dil * (KW - 1) / 2, span1 = dil * (KW - 1);
+    const int A = (P + left1 + 3) & ~3;            // staged input window starts at the 16-byte aligned time q0 - A
+    const int shift = A - (P + left1);
+    const int xw4 = (FT + span1 + shift + 3) >> 2;
+    const int xw_pad = xw4 * 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* t1s = (float*)smem;                     // [VR][T1P]
+    float* xs = t1s + VR * T1P;                    // [VCI][xw_pad]
+    float* ws = xs + VCI * xw_pad;                 // [VCI][KW][VR]
+
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * VT2;               // first output column (multiple of 4)
+    const int w0 = q0 - P;                         // time of t1 window column 0
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int lin = len_in ? min(len_in[b], T) : T;
+    const float* yb = y + (size_t)b * C * T;
+    const bool vec_ok = (T & 3) == 0 && ((uintptr_t)y & 15) == 0;
+
+    f32x16 acc[RT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    auto stage_w = [&](const float* Wt, int c0) {
+        for (int i = threadIdx.x; i < VCI * KW * (VR / 4); i += 256) {
+            const int r4 = i % (VR / 4), ck = i / (VR / 4);
+            *(float4*)(ws + ck * VR + r4 * 4) = *(const float4*)(Wt + ((size_t)c0 * KW + ck) * rows_pad + r4 * 4);
+        }
+    };
+
+    // ---------------- conv1 (dilated): t1 window column i <-> time w0 + i
+    zero_acc();
+    for (int c0 = 0; c0 < C; c0 += VCI) {
+        __syncthreads();
+        for (int c = wave; c < VCI; c += 4) {
+            const float* row = yb + (size_t)(c0 + c) * T;
+            for (int i4 = lane; i4 < xw4; i4 += 64) {
+                const int pos = q0 - A + i4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (vec_ok && pos >= 0 && pos + 3 < lin) {
+                    v = *(const float4*)(row + pos);
+                } else {
+                    if (pos >= 0 && pos < lin) v.x = row[pos];
+                    if (pos + 1 >= 0 && pos + 1 < lin) v.y = row[pos + 1];
+                    if (pos + 2 >= 0 && pos + 2 < lin) v.z = row[pos + 2];
+                    if (pos + 3 >= 0 && pos + 3 < lin) v.w = row[pos + 3];
+                }
+                v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
+                *(float4*)(xs + c * xw_pad + i4 * 4) = v;
+            }
+        }
+        stage_w(W1, c0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VCI / 2; ++j) {
+            const int c = 2 * j + h;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const float x = xs[c * xw_pad + wave * 32 + r32 + kw * dil + shift];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri)
+                    acc[ri] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(c * KW + kw) * VR + ri * 32 + r32], x, acc[ri], 0, 0, 0);
+            }
+        }
+    }
+    // t1 = conv1 + bias (the unfused conv1 epilogue: no residual, scale 1), then what the unfused conv2 does while staging
+    // its window: zero outside [0, len), LeakyReLU.  D[row = (reg&3) + 8(reg>>2) + 4h][column = r32]
+    {
+        const int col = wave * 32 + r32;
+        const int t = w0 + col;
+        const bool inside = t >= 0 && t < lin;
+#pragma unroll
+        for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = 0.f;
+                if (inside && row < C) { v = acc[ri][r] + b1[row]; v *= 1.0f; v = lrelu(v, slope); }
+                t1s[row * T1P + col] = v;
+            }
+    }
+    // ---------------- conv2 (undilated) out of the LDS image: output column c <-> time w0 + half + c, reads t1 columns c .. c + KW - 1
+    zero_acc();
+    for (int c0 = 0; c0 < C; c0 += VCI) {
+        __syncthreads();                            // first pass: t1s complete; later passes: ws free again
+        stage_w(W2, c0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VCI / 2; ++j) {
+            const int c = c0 + 2 * j + h;
+            const int cl = 2 * j + h;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ci = min(wave * 32 + r32 + kw, FT - 1);          // columns past the window feed only discarded outputs
+                const float x = t1s[c * T1P + ci];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri)
+                    acc[ri] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(cl * KW + kw) * VR + ri * 32 + r32], x, acc[ri], 0, 0, 0);
+            }
+        }
+    }
+    {
+        const int cc = wave * 32 + r32;             // conv2 output column
+        const int t = w0 + half + cc;
+        if (cc >= P - half && cc < P - half + VT2 && t < T) {
+            float* outb = out + (size_t)b * C * T;
+#pragma unroll
+            for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= C) continue;
+                    const size_t o = (size_t)row * T + t;
+                    float v = acc[ri][r] + b2[row];
+                    v += yb[o];
+                    v *= out_scale;
+                    if (accumulate) v += outb[o];
+                    outb[o] = v;
+                }
+        }
+    }
 }
 
 // ---- K13: conv_post (C -> 1, k = KW) on lrelu(x), tanh, *32767, clip, truncate to int16.  HBM-bound:
@@ -281,6 +432,37 @@ int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
             case 11: launch_conv<11, false, 4>(a, st); break;
             default: *err = "conv: kernel width must be 3, 7 or 11"; return -22;
         }
+    }
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
+namespace {
+template <int KW, int RT, int VCI>
+void launch_mrf(const vv_mrf_args* a, hipStream_t st) {
+    constexpr int E = (KW - 1 + 3) & ~3, VT2 = FT - E, half = (KW - 1) / 2, P = E - half;
+    const int left1 = a->dil * (KW - 1) / 2, span1 = a->dil * (KW - 1);
+    const int Aw = (P + left1 + 3) & ~3;
+    const int xw_pad = ((FT + span1 + (Aw - (P + left1)) + 3) >> 2) * 4;
+    const size_t lds = (size_t)(RT * 32 * (FT + 4) + VCI * xw_pad + VCI * KW * RT * 32) * sizeof(float);
+    dim3 grid((a->T + VT2 - 1) / VT2, 1, a->B);
+    mrf_pair_kernel<KW, RT, VCI><<<grid, 256, lds, st>>>(a->y, a->W1, a->b1, a->W2, a->b2, a->out, a->C, a->rows_pad, a->T, a->dil, a->slope,
+                                                       a->out_scale, a->accumulate, a->len_in);
+}
+}  // namespace
+
+int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
+    if (a->B <= 0 || a->T <= 0 || (a->C != 32 && a->C != 64)) { *err = "mrf_resblock: fused form needs C = 32 or 64 (the intermediate tile must fit the CU)"; return -22; }
+    if (a->rows_pad != 64 || ((uintptr_t)a->W1 % 16) || ((uintptr_t)a->W2 % 16)) { *err = "mrf_resblock: weight slabs [C_pad8][KW][64], 16-byte aligned"; return -22; }
+    if (a->dil < 1 || a->dil > 5) { *err = "mrf_resblock: dilation 1..5"; return -22; }
+    if (a->out == a->y) { *err = "mrf_resblock: out must not alias y (neighbouring workgroups read y's halo)"; return -22; }
+    const bool wide = a->C == 64;
+    switch (a->KW) {
+        case 3: wide ? launch_mrf<3, 2, 8>(a, st) : launch_mrf<3, 1, 8>(a, st); break;
+        case 7: wide ? launch_mrf<7, 2, 4>(a, st) : launch_mrf<7, 1, 4>(a, st); break;
+        case 11: wide ? launch_mrf<11, 2, 4>(a, st) : launch_mrf<11, 1, 4>(a, st); break;
+        default: *err = "mrf_resblock: kernel width must be 3, 7 or 11"; return -22;
     }
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }

@@ -81,6 +81,12 @@ class vv_conv_args(C.Structure):
                 ("pre_slope", C.c_float), ("out_scale", C.c_float), ("len_in", C.c_void_p)]
 
 
+class vv_mrf_args(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("KW", C.c_int32), ("dil", C.c_int32), ("rows_pad", C.c_int32),
+                ("accumulate", C.c_int32), ("slope", C.c_float), ("out_scale", C.c_float), ("len_in", C.c_void_p)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "vv_version": (C.c_char_p, []),
@@ -100,6 +106,7 @@ EXPORTS = {
     "vv_decode_into": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vv_ws_generation": (C.c_uint64, [C.c_void_p]),
+    "vv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vv_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vv_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_gemm": (C.c_int, [C.c_void_p, C.POINTER(vv_gemm_args), C.c_void_p]),
@@ -107,6 +114,7 @@ EXPORTS = {
     "vv_layernorm": (C.c_int, [C.c_void_p, C.POINTER(vv_ln_args), C.c_void_p]),
     "vv_posconv": (C.c_int, [C.c_void_p, C.POINTER(vv_posconv_args), C.c_void_p]),
     "vv_conv1d": (C.c_int, [C.c_void_p, C.POINTER(vv_conv_args), C.c_void_p]),
+    "vv_mrf_resblock": (C.c_int, [C.c_void_p, C.POINTER(vv_mrf_args), C.c_void_p]),
     "vv_conv_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "vv_mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -359,6 +367,10 @@ class HipSynth:
             self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, x.numel(), stats.data_ptr(),
                                                     out.data_ptr(), self._stream()))
         return out
+
+    def set_option(self, name: str, value: int):
+        """Context switches of the C ABI (vv_set_option), e.g. ``fuse_mrf`` 0/1."""
+        self._check(self.lib.vv_set_option(self.ctx, name.encode(), int(value)))
 
     # ------------------------------------------------------------------ profiling
     def prof_enable(self, on: bool):
