@@ -223,6 +223,9 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
+    if os.environ.get("VV_BENCH_DUMP_MAPS"):          # diagnostics for profiler-side crashes: the loaded images, so a raw stack can be symbolised
+        with open("/proc/self/maps") as src, open(os.environ["VV_BENCH_DUMP_MAPS"], "w") as dst:
+            dst.write(src.read())
     if a.workload == "mixed256":
         batches, audio_s_rank, nb, fill = make_mixed_inputs(spec, a.batch, rank, world, device)
     else:

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""GEMM A/B at the DiT block shapes (M = 102,400): every library on the command line is loaded into ONE process, timed in
+interleaved rounds and checked against the first library's output.   python tools/gemm_ab.py [rounds] lib1.so lib2.so ..."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vietvoice_tts_amd import runtime as rt
+from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+
+rounds = int(sys.argv[1])
+libs = sys.argv[2:]
+spec = ModelSpec.tiny()
+w = make_synthetic_weights(spec)
+dev = "cuda:0"
+engs = []
+for p in libs:
+    rt._lib = None
+    rt._lib = rt.load_library(p)
+    engs.append(rt.HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4))
+M = 102400
+g = torch.Generator().manual_seed(0)
+shapes = [("qkv_rope", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0)]
+cs = torch.rand(1600, 64, device=dev)
+pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
+st = torch.cuda.current_stream().cuda_stream
+tot = {p: 0.0 for p in libs}
+for name, mode, N, K, act in shapes:
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+    gate = torch.randn(N, generator=g).to(dev)
+    outs, args = [], []
+    for e in engs:
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        a = rt.vv_gemm_args()
+        a.dtype, a.out_dtype, a.mode, a.act = rt.VV_BF16, rt.VV_BF16, mode, act
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K
+        a.bias, a.gate = bias.data_ptr(), (gate.data_ptr() if mode == 3 else None)
+        if mode == 1:
+            a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
+            a.rope_cs_q = a.rope_cs_k = cs.data_ptr(); a.rope_pos = pos.data_ptr()
+        for _ in range(2):
+            assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
+        outs.append(out); args.append(a)
+    torch.cuda.synchronize()
+    diffs = [float((o.float() - outs[0].float()).abs().max()) for o in outs[1:]]
+    times = [[] for _ in libs]
+    for r in range(rounds):
+        for i, (e, a) in enumerate(zip(engs, args)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                e.lib.vv_gemm(e.ctx, C.byref(a), st)
+            e1.record(); torch.cuda.synchronize()
+            times[i].append(e0.elapsed_time(e1) / 10)
+    line = f"{name:15s} N={N} K={K}:"
+    for i, p in enumerate(libs):
+        t = sorted(times[i]); med = t[len(t) // 2]
+        tot[p] += med
+        line += f"  {os.path.basename(p)[9:-3]} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
+    print(line + f"  | max diff vs first {diffs}", flush=True)
+print("sum of the four (one DiT block): " + "  ".join(f"{os.path.basename(p)[9:-3]} {tot[p]*1e3:.1f} us" for p in libs), flush=True)

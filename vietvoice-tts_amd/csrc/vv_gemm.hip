@@ -331,6 +331,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit.
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
+#ifdef VV_GEMM_G1
+    // G1: (1) every tile issues exactly 16 output stores per wave -- buffer stores whose out-of-range lanes carry an offset past
+    // num_records (dropped by the hardware) instead of an exec-masked global store that the compiler may branch around -- so the
+    // first K-tile of EVERY tile may leave the previous tile's stores in flight (vmcnt(24)); 16 dropped stores in the prologue
+    // make that true for a block's first tile too.  (2) bias / gate vectors are prefetched one tile ahead, one coalesced dword
+    // per lane (lane i = feature wc*64 + i), and handed to the lanes that need them with ds_bpermute: no VGPR-destination
+    // vector load sits at the top of a tile or in the epilogue any more (its in-order vmcnt wait drained the 16 stores).
+    constexpr bool G1 = sizeof(To) == 2 && MODE != MODE_GATE_RES;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
+    auto lane_get = [&](float v, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+    };
+    // a dword load hipcc does not count: no compiler-inserted vmcnt for it (that wait would drain the stores and the LDS-DMA
+    // ring); its completion is covered by the explicit counted wait at the end of the epilogue, which also names the
+    // destination so that nothing reads or copies it earlier (cdna guide 5.7 item 1, form ii)
+    auto load_async = [&](const float* p) {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    };
+#else
+    constexpr bool G1 = false;
+#endif
     unsigned voff_w[2][2];     // [n-half][piece]  relative to the tile's first weight row
     int loc_a[2];              // [piece]          token row of the piece inside the tile (m-half 0); + 64 for m-half 1
     unsigned cbyte[2];
@@ -441,6 +464,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         stage(T0{}, bm0, bn0, 0, 0); stage(T1{}, bm0, bn0, 0, 0); stage(T2{}, bm0, bn0, 0, 0); stage(T3{}, bm0, bn0, 0, 0);
         stage(T0{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);
     }
+#ifdef VV_GEMM_G1
+    float bias_nx = 0.f, gate_nx = 0.f;
+    if constexpr (G1) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)       // past num_records: dropped by the hardware, but issued and counted (distinct offsets: not mergeable)
+            __builtin_amdgcn_raw_buffer_store_b128(z4, rs_c, (int)(0x7ffffff0u - 16u * (unsigned)i), 0, 0);
+        if (e.bias) bias_nx = e.bias[tile_bn(0) + wc * 64 + lane];              // compiler-counted: waited for before the loop
+        if constexpr (MODE == MODE_GATE_STORE) gate_nx = e.gate[tile_bn(0) + wc * 64 + lane];
+    }
+#endif
     VV_WAITVM(8);
     bar();
     if (g == 1) bar();                                         // stagger group 1 by one segment
@@ -452,11 +487,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         const bool last = it + 1 == n_my;
         const int bm_n = last ? bm : tile_bm(it + 1), bn_n = last ? bn : tile_bn(it + 1);
         // accumulators start at the bias (feature-only), so the epilogue has no bias pass
+#ifdef VV_GEMM_G1
+        const float bias_cur = bias_nx;
+#endif
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef VV_GEMM_G1
+                if constexpr (G1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b4[j] = lane_get(bias_cur, nh * 32 + ni * 16 + cq * 4 + j);
+                } else
+#endif
                 if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
@@ -466,7 +510,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // first K-tile after a full bf16 tile store (every wave issued exactly 16 stores): leave those stores in flight
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
-        if constexpr (MODE == MODE_STORE) {
+        if constexpr (G1) {
+            ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);             // 16 stores (real or dropped) always precede a tile
+        } else if constexpr (MODE == MODE_STORE) {
             if (stores_pending) ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
             else ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
         } else {
@@ -499,7 +545,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
+#ifdef VV_GEMM_G1
+                    float4 gt;
+                    if constexpr (G1) {
+                        gt.x = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 0); gt.y = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 1);
+                        gt.z = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 2); gt.w = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 3);
+                    } else gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
+#else
                     const float4 gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
+#endif
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -575,6 +629,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
                     const int m = bm + g * 128 + ps * 32 + lr;
                     const int n0 = bn + wc * 64 + ch * 8;
+#ifdef VV_GEMM_G1
+                    if constexpr (G1) {
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                        const u32x4 vv = {val.x, val.y, val.z, val.w};
+                        const unsigned off = (m < M && n0 < e.n_store) ? ((unsigned)m * (unsigned)ldc + (unsigned)n0) * 2u : 0x7ffffff0u;
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)off, 0, 2);       // nt; out-of-range lanes are dropped by the resource bound
+                    } else
+#endif
                     if (m < M && n0 < e.n_store && !(VV_DBG(e) & 128)) {
                         if (VV_DBG(e) & 1024) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
                         else {   // streamed once, read by the next kernel from HBM anyway
@@ -584,7 +646,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         }
                     }
                 }
+#ifdef VV_GEMM_G1
+                if constexpr (G1) {
+                    // next tile's bias / gate, issued behind the first pass's 4 stores (hipcc drains vmcnt before the first
+                    // read-back of the staging region: the prefetch must not sit in front of that wait) and ahead of the other 12
+                    if (ps == 0) {
+                        if (e.bias) bias_nx = load_async(e.bias + bn_n + wc * 64 + lane);
+                        if constexpr (MODE == MODE_GATE_STORE) gate_nx = load_async(e.gate + bn_n + wc * 64 + lane);
+                    }
+                }
+#endif
             }
+#ifdef VV_GEMM_G1
+            // the two prefetch loads sit in front of the last 12 stores: after this wait they have landed (those stores stay in
+            // flight), and naming the registers keeps every use / copy of them below it
+            if constexpr (G1) asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_nx), "+v"(gate_nx)::"memory");
+#endif
         } else {
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
@@ -673,7 +750,8 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
     if constexpr (sizeof(T) == 2) {
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
-        if (big && !(VV_DBG(e) & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31))
+        if (big && !(VV_DBG(e) & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31) &&
+            (size_t)M * ldc * sizeof(To) < ((size_t)1 << 31))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
     if (big && (VV_DBG(e) & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);

@@ -150,15 +150,16 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
 // unfused kernel's contraction order (channel pairs ascending, taps ascending inside a pair) and epilogue arithmetic, so the
 // result is BIT-IDENTICAL to vv_conv1d(conv1) followed by vv_conv1d(conv2, resid = y).  HBM traffic per pair: y read once
 // (+ halo), out written once -- 2 tensor passes instead of 5.
-constexpr int FT = 128;       // intermediate columns per workgroup (4 waves x one 32-column MFMA tile)
-
-template <int KW, int RT, int VCI>
+// CT = 32-column MFMA tiles per wave: the window is FT = 128 * CT columns (C = 32 takes CT = 2: same accumulator registers as
+// C = 64 with CT = 1, half the halo recompute).
+template <int KW, int RT, int VCI, int CT>
 __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restrict__ y, const float* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
                                                           int C, int rows_pad, int T, int dil, float slope, float out_scale, int accumulate,
                                                           const int* __restrict__ len_in) {
 #pragma clang fp contract(off)      // same separate add / multiply roundings as conv_mfma_kernel's epilogue
     constexpr int VR = RT * 32;
+    constexpr int FT = 128 * CT;                   // intermediate columns per workgroup
     constexpr int half = (KW - 1) / 2;
     constexpr int E = (KW - 1 + 3) & ~3;           // columns of the window that are halo only
     constexpr int VT2 = FT - E;                    // output columns per workgroup
@@ -184,12 +185,14 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
     const float* yb = y + (size_t)b * C * T;
     const bool vec_ok = (T & 3) == 0 && ((uintptr_t)y & 15) == 0;
 
-    f32x16 acc[RT];
+    f32x16 acc[RT][CT];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
     };
     auto stage_w = [&](const float* Wt, int c0) {
         for (int i = threadIdx.x; i < VCI * KW * (VR / 4); i += 256) {
@@ -226,17 +229,23 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
             const int c = 2 * j + h;
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
-                const float x = xs[c * xw_pad + wave * 32 + r32 + kw * dil + shift];
+                float a[RT], x[CT];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri) a[ri] = ws[(c * KW + kw) * VR + ri * 32 + r32];
+#pragma unroll
+                for (int ti = 0; ti < CT; ++ti) x[ti] = xs[c * xw_pad + (wave * CT + ti) * 32 + r32 + kw * dil + shift];
 #pragma unroll
                 for (int ri = 0; ri < RT; ++ri)
-                    acc[ri] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(c * KW + kw) * VR + ri * 32 + r32], x, acc[ri], 0, 0, 0);
+#pragma unroll
+                    for (int ti = 0; ti < CT; ++ti) acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], x[ti], acc[ri][ti], 0, 0, 0);
             }
         }
     }
     // t1 = conv1 + bias (the unfused conv1 epilogue: no residual, scale 1), then what the unfused conv2 does while staging
     // its window: zero outside [0, len), LeakyReLU.  D[row = (reg&3) + 8(reg>>2) + 4h][column = r32]
-    {
-        const int col = wave * 32 + r32;
+#pragma unroll
+    for (int ti = 0; ti < CT; ++ti) {
+        const int col = (wave * CT + ti) * 32 + r32;
         const int t = w0 + col;
         const bool inside = t >= 0 && t < lin;
 #pragma unroll
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int row = ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = 0.f;
-                if (inside && row < C) { v = acc[ri][r] + b1[row]; v *= 1.0f; v = lrelu(v, slope); }
+                if (inside && row < C) { v = acc[ri][ti][r] + b1[row]; v *= 1.0f; v = lrelu(v, slope); }
                 t1s[row * T1P + col] = v;
             }
     }
@@ -261,16 +270,21 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
             const int cl = 2 * j + h;
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
-                const int ci = min(wave * 32 + r32 + kw, FT - 1);          // columns past the window feed only discarded outputs
-                const float x = t1s[c * T1P + ci];
+                float a[RT], x[CT];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri) a[ri] = ws[(cl * KW + kw) * VR + ri * 32 + r32];
+#pragma unroll
+                for (int ti = 0; ti < CT; ++ti) x[ti] = t1s[c * T1P + min((wave * CT + ti) * 32 + r32 + kw, FT - 1)];   // past the window: discarded outputs only
 #pragma unroll
                 for (int ri = 0; ri < RT; ++ri)
-                    acc[ri] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[(cl * KW + kw) * VR + ri * 32 + r32], x, acc[ri], 0, 0, 0);
+#pragma unroll
+                    for (int ti = 0; ti < CT; ++ti) acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ri], x[ti], acc[ri][ti], 0, 0, 0);
             }
         }
     }
-    {
-        const int cc = wave * 32 + r32;             // conv2 output column
+#pragma unroll
+    for (int ti = 0; ti < CT; ++ti) {
+        const int cc = (wave * CT + ti) * 32 + r32;  // conv2 output column
         const int t = w0 + half + cc;
         if (cc >= P - half && cc < P - half + VT2 && t < T) {
             float* outb = out + (size_t)b * C * T;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
                     const int row = ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row >= C) continue;
                     const size_t o = (size_t)row * T + t;
-                    float v = acc[ri][r] + b2[row];
+                    float v = acc[ri][ti][r] + b2[row];
                     v += yb[o];
                     v *= out_scale;
                     if (accumulate) v += outb[o];
@@ -439,15 +453,15 @@ int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
 }
 
 namespace {
-template <int KW, int RT, int VCI>
+template <int KW, int RT, int VCI, int CT>
 void launch_mrf(const vv_mrf_args* a, hipStream_t st) {
-    constexpr int E = (KW - 1 + 3) & ~3, VT2 = FT - E, half = (KW - 1) / 2, P = E - half;
+    constexpr int FT = 128 * CT, E = (KW - 1 + 3) & ~3, VT2 = FT - E, half = (KW - 1) / 2, P = E - half;
     const int left1 = a->dil * (KW - 1) / 2, span1 = a->dil * (KW - 1);
     const int Aw = (P + left1 + 3) & ~3;
     const int xw_pad = ((FT + span1 + (Aw - (P + left1)) + 3) >> 2) * 4;
     const size_t lds = (size_t)(RT * 32 * (FT + 4) + VCI * xw_pad + VCI * KW * RT * 32) * sizeof(float);
     dim3 grid((a->T + VT2 - 1) / VT2, 1, a->B);
-    mrf_pair_kernel<KW, RT, VCI><<<grid, 256, lds, st>>>(a->y, a->W1, a->b1, a->W2, a->b2, a->out, a->C, a->rows_pad, a->T, a->dil, a->slope,
+    mrf_pair_kernel<KW, RT, VCI, CT><<<grid, 256, lds, st>>>(a->y, a->W1, a->b1, a->W2, a->b2, a->out, a->C, a->rows_pad, a->T, a->dil, a->slope,
                                                        a->out_scale, a->accumulate, a->len_in);
 }
 }  // namespace
@@ -459,9 +473,9 @@ int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
     if (a->out == a->y) { *err = "mrf_resblock: out must not alias y (neighbouring workgroups read y's halo)"; return -22; }
     const bool wide = a->C == 64;
     switch (a->KW) {
-        case 3: wide ? launch_mrf<3, 2, 8>(a, st) : launch_mrf<3, 1, 8>(a, st); break;
-        case 7: wide ? launch_mrf<7, 2, 4>(a, st) : launch_mrf<7, 1, 4>(a, st); break;
-        case 11: wide ? launch_mrf<11, 2, 4>(a, st) : launch_mrf<11, 1, 4>(a, st); break;
+        case 3: wide ? launch_mrf<3, 2, 8, 1>(a, st) : launch_mrf<3, 1, 8, 2>(a, st); break;
+        case 7: wide ? launch_mrf<7, 2, 4, 1>(a, st) : launch_mrf<7, 1, 4, 2>(a, st); break;
+        case 11: wide ? launch_mrf<11, 2, 4, 1>(a, st) : launch_mrf<11, 1, 4, 2>(a, st); break;
         default: *err = "mrf_resblock: kernel width must be 3, 7 or 11"; return -22;
     }
     hipError_t he = hipGetLastError();
