@@ -106,8 +106,9 @@ int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref
                    void* stream);
 uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
 
-/* Context switches (explicit API, never the environment).  "fuse_mrf" (default 1): run the MRF resblock pairs of the C <= 64
- * vocoder stages through vv_mrf_resblock's fused kernel; 0 = two vv_conv1d launches per pair (bit-identical results). */
+/* Context switches (explicit API, never the environment).  "fuse_mrf": run the MRF resblock pairs of the C <= 64 vocoder
+ * stages through vv_mrf_resblock's fused kernel -- 0 never (two vv_conv1d launches per pair), 1 always, 2 (default) for
+ * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way. */
 int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */

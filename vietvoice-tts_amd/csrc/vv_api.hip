@@ -43,7 +43,8 @@ struct vv_ctx {
     size_t ar_cap = 0, ar_off = 0;
     uint64_t ws_generation = 0;         // bumped whenever ws is reallocated
     int* d_mult = nullptr;              // decode length multipliers
-    bool fuse_mrf = true;               // K12: MRF pairs of the C <= 64 stages run fused through LDS (vv_set_option "fuse_mrf")
+    int fuse_mrf = 2;                   // K12 fused MRF pairs (C <= 64 stages): 0 never, 1 always, 2 auto = for decodes of <= 8 items
+                                        // (fewer launches win when the stage is launch-bound; at B = 32 the halo recompute costs 1.3 %)
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -590,7 +591,7 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
                 const bool last = b == g.voc_n_dil - 1;
                 float* dst = last ? acc : ((y == ya) ? yb : ya);
                 const int kw = g.voc_res_kernels[a], dil = g.voc_res_dilations[b];
-                if (c->fuse_mrf && (C == 32 || C == 64) && (kw == 3 || kw == 7 || kw == 11)) {
+                if ((c->fuse_mrf == 1 || (c->fuse_mrf == 2 && B <= 8)) && (C == 32 || C == 64) && (kw == 3 || kw == 7 || kw == 11)) {
                     // K12 fused through LDS: the intermediate of the pair never reaches HBM (bit-identical to the two launches below)
                     vv_mrf_args m{};
                     m.y = y; m.W1 = c->Wf(q + ".conv1.weight"); m.b1 = c->Wf(q + ".conv1.bias"); m.W2 = c->Wf(q + ".conv2.weight"); m.b2 = c->Wf(q + ".conv2.bias");
@@ -623,7 +624,10 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
-    if (!strcmp(name, "fuse_mrf")) { c->fuse_mrf = value != 0; return 0; }
+    if (!strcmp(name, "fuse_mrf")) {
+        if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: fuse_mrf takes 0 (off), 1 (on) or 2 (auto)");
+        c->fuse_mrf = value; return 0;
+    }
     return c->fail(-22, "vv_set_option: unknown option '%s'", name);
 }
 

@@ -18,6 +18,12 @@
 // XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
 #include "vv_common.h"
 #include "vv_kernels.h"
+// G1 (round 2): counted output stores + async bias / gate prefetch in the persistent kernel; measured -2.8 ... -4.3 % on the
+// out-proj / FF1 / FF2 shapes, bit-identical results (profiles/r02/gemm_notes.md).  -DVV_GEMM_NO_G1 builds the round-1 epilogue
+// for A/B runs (tools/build_variants.py, tools/gemm_ab.py).
+#if !defined(VV_GEMM_NO_G1) && !defined(VV_GEMM_ABLATE)
+#define VV_GEMM_G1 1
+#endif
 #include <atomic>
 #include <cstdlib>
 #include <mutex>

@@ -473,9 +473,11 @@ int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
     if (a->out == a->y) { *err = "mrf_resblock: out must not alias y (neighbouring workgroups read y's halo)"; return -22; }
     const bool wide = a->C == 64;
     switch (a->KW) {
-        case 3: wide ? launch_mrf<3, 2, 8, 1>(a, st) : launch_mrf<3, 1, 8, 2>(a, st); break;
-        case 7: wide ? launch_mrf<7, 2, 4, 1>(a, st) : launch_mrf<7, 1, 4, 2>(a, st); break;
-        case 11: wide ? launch_mrf<11, 2, 4, 1>(a, st) : launch_mrf<11, 1, 4, 2>(a, st); break;
+        // 128-column windows for both widths: a 256-column window for C = 32 (half the halo recompute) measured SLOWER at the
+        // headline batch (conv class 199 vs 193 ms, profiles/r02/vocoder_notes.md): occupancy beats the halo
+        case 3: wide ? launch_mrf<3, 2, 8, 1>(a, st) : launch_mrf<3, 1, 8, 1>(a, st); break;
+        case 7: wide ? launch_mrf<7, 2, 4, 1>(a, st) : launch_mrf<7, 1, 4, 1>(a, st); break;
+        case 11: wide ? launch_mrf<11, 2, 4, 1>(a, st) : launch_mrf<11, 1, 4, 1>(a, st); break;
         default: *err = "mrf_resblock: kernel width must be 3, 7 or 11"; return -22;
     }
     hipError_t he = hipGetLastError();
