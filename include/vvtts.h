@@ -138,6 +138,8 @@ typedef struct vv_gemm_args {
     const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
     int32_t tile;   /* 0 = auto (256x256 tile when M >= 4096 and N % 256 == 0), 128 or 256 to force */
     const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
+    int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
+                                  needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */
 } vv_gemm_args;
 int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 
@@ -218,6 +220,8 @@ int vv_groupnorm(vv_ctx* ctx, const float* x, float* y, const float* gamma, cons
                  float eps, int act, void* stream);
 /* out[pos][2i] = cos[pos][2i], out[pos][2i+1] = sin[pos][2i]  (tables with duplicated pairs, n rows x 64) */
 int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
+/* out[r][0..63] = compact[pos[r]][0..63]: the compact table gathered once per call for every packed row */
+int vv_rope_rows(vv_ctx* ctx, const float* compact, const int32_t* pos, float* out, int rows, void* stream);
 int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
 
 /* ---- reference-clip ingest on the device.  Together they replace the arithmetic of

@@ -19,9 +19,10 @@ for p in libs:
     engs.append(rt.HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4))
 M = 102400
 g = torch.Generator().manual_seed(0)
-shapes = [("qkv_rope", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0)]
+shapes = [("qkv_rope", 1, 3072, 1024, 0), ("qkv_rope_rows", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0)]
 cs = torch.rand(1600, 64, device=dev)
 pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
+cs_rows = cs[pos.long()].contiguous()            # what vv_rope_rows builds once per call
 st = torch.cuda.current_stream().cuda_stream
 tot = {p: 0.0 for p in libs}
 for name, mode, N, K, act in shapes:
@@ -39,6 +40,8 @@ for name, mode, N, K, act in shapes:
         if mode == 1:
             a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr(); a.rope_pos = pos.data_ptr()
+            if name.endswith("_rows") and hasattr(a, "rope_by_row"):
+                a.rope_cs_q = a.rope_cs_k = cs_rows.data_ptr(); a.rope_by_row = 1
         for _ in range(2):
             assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
         outs.append(out); args.append(a)
@@ -53,10 +56,15 @@ for name, mode, N, K, act in shapes:
                 e.lib.vv_gemm(e.ctx, C.byref(a), st)
             e1.record(); torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1) / 10)
+    if name == "qkv_rope":
+        qkv_ref = outs[0].clone()
+    if name == "qkv_rope_rows":
+        diffs.append(("vs position-table path", float((outs[0].float() - qkv_ref.float()).abs().max())))
     line = f"{name:15s} N={N} K={K}:"
     for i, p in enumerate(libs):
         t = sorted(times[i]); med = t[len(t) // 2]
-        tot[p] += med
+        if name != "qkv_rope":
+            tot[p] += med
         line += f"  {os.path.basename(p)[9:-3]} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
     print(line + f"  | max diff vs first {diffs}", flush=True)
-print("sum of the four (one DiT block): " + "  ".join(f"{os.path.basename(p)[9:-3]} {tot[p]*1e3:.1f} us" for p in libs), flush=True)
+print("sum of qkv_rope_rows + out + ff1 + ff2 (one DiT block): " + "  ".join(f"{os.path.basename(p)[9:-3]} {tot[p]*1e3:.1f} us" for p in libs), flush=True)

@@ -129,14 +129,15 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 // ---- GEMM helper over bound weights -------------------------------------------------------
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
-         const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr) {
+         const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
+         int rope_by_row = 0) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
     g.A = A; g.lda = lda; g.W = c->W(wname); g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
-    g.rope_pos = rope_pos;
+    g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -409,6 +410,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     Need nd;
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
     nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * htab.size());
+    nd.add(4ull * R * 64); nd.add(4ull * R * 64);
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
@@ -423,12 +425,16 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     float* csq = carve<float>(c, (size_t)N * 64);
     float* csk = carve<float>(c, (size_t)N * 64);
     int* tab = carve<int>(c, htab.size());
+    float* csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
+    float* csk_rows = carve<float>(c, R * 64);
     HIPCHK(c, hipMemcpyAsync(tab, htab.data(), sizeof(int) * htab.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));                 // htab is a local: the copy must be done before it goes away
     const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
-    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, csq, csk};
+    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, csq_rows, csk_rows};
     KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
     KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
+    KCHK(c, vvk_rope_rows(csq, row_pos, csq_rows, (int)R, st, &m__));
+    KCHK(c, vvk_rope_rows(csk, row_pos, csk_rows, (int)R, st, &m__));
 
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
@@ -470,7 +476,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, row_pos)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, row_pos, 1)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
                 t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
@@ -702,6 +708,9 @@ int vv_mel(vv_ctx* c, const int16_t* audio, int ld_audio, const int32_t* audio_l
 }
 int vv_groupnorm(vv_ctx* c, const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act, void* st) {
     SINGLE(c, vvk_groupnorm(x, y, gamma, beta, B, C, T, G, eps, act, (hipStream_t)st, &m__));
+}
+int vv_rope_rows(vv_ctx* c, const float* compact, const int32_t* pos, float* out, int rows, void* st) {
+    SINGLE(c, vvk_rope_rows(compact, pos, out, rows, (hipStream_t)st, &m__));
 }
 int vv_rope_compact(vv_ctx* c, const float* cos_t, const float* sin_t, float* out, int n, void* st) {
     SINGLE(c, vvk_rope_compact(cos_t, sin_t, out, n, (hipStream_t)st, &m__));

@@ -302,6 +302,14 @@ __global__ __launch_bounds__(256) void rope_compact_kernel(const float* __restri
     out[(size_t)pos * 64 + 2 * pr + 1] = s[(size_t)pos * 64 + 2 * pr];
 }
 
+__global__ __launch_bounds__(256) void rope_rows_kernel(const float* __restrict__ cs, const int* __restrict__ pos, float* __restrict__ out, int rows) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one float4 of one row
+    if (i >= (size_t)rows * 16) return;
+    const size_t r = i >> 4;
+    const int q = (int)(i & 15);
+    *(float4*)(out + r * 64 + q * 4) = *(const float4*)(cs + (size_t)pos[r] * 64 + q * 4);
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(float* __restrict__ x, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = x[i];
@@ -428,6 +436,14 @@ int vvk_groupnorm(const float* x, float* y, const float* gamma, const float* bet
     VVK_CHECK_LAUNCH();
     return 0;
 }
+int vvk_rope_rows(const float* cs, const int* pos, float* out, int rows, hipStream_t st, const char** err) {
+    if (rows <= 0 || !cs || !pos || !out) { *err = "rope_rows: bad arguments"; return -22; }
+    rope_rows_kernel<<<(unsigned)(((size_t)rows * 16 + 255) / 256), 256, 0, st>>>(cs, pos, out, rows);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
 int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err) {
     if (n <= 0) { *err = "rope_compact: empty"; return -22; }
     rope_compact_kernel<<<(n * 32 + 255) / 256, 256, 0, st>>>(c, s, out, n);

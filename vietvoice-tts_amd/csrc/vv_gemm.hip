@@ -50,6 +50,7 @@ struct EpiArgs {
     int n_store;
     int seq_n;
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
+    int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
 #ifdef VV_GEMM_ABLATE
     int dbg;     // timing-only ablations, A/B build for tools/gemm_bench.py ONLY (libvvtts_hip_ablate.so, selected with VVTTS_LIB):
@@ -583,12 +584,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     const int mi = (ps & 1) * 2 + k;
                     const int lr = k * 16 + r16;
                     const int m = bm + g * 128 + ps * 32 + lr;
-                    const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[min(m, M - 1)] : min(m, M - 1) % e.seq_n) : 0;
-                    // RoPE: one 16-byte (cos, sin, cos, sin) load per 4 outputs from the compact table, all four issued first
+                    // RoPE: one 16-byte (cos, sin, cos, sin) load per 4 outputs from the compact table, all four issued first.
+                    // With row-gathered tables (cs_by_row) the address depends on m alone: no position load, no second wait; the
+                    // v columns (a third of the tiles) touch neither.
                     float4 cs4[2][2];
                     bool do_rope = false;
+                    int pos = 0;
                     if constexpr (MODE == MODE_QKV_ROPE) {
-                        do_rope = bn + wc * 64 < 2 * e.rope_dim && e.cs_q != nullptr;
+                        const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim;
+                        do_rope = rope_tile && e.cs_q != nullptr;
+                        if (rope_tile) pos = e.cs_by_row ? min(m, M - 1) : (e.pos_tab ? e.pos_tab[min(m, M - 1)] : min(m, M - 1) % e.seq_n);
                         if (do_rope) {
                             const float* tab = (bn + wc * 64 >= e.rope_dim ? e.cs_k : e.cs_q) + (size_t)pos * 64;
 #pragma unroll
@@ -783,7 +788,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
-    e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos;
+    e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
 #ifdef VV_GEMM_ABLATE
     {   // ablation build only (never the shipped library): bits from the environment, read once per process
         static const int dbg_env = [] { const char* d = getenv("VV_GEMM_DBG"); return d ? atoi(d) : 0; }();

@@ -44,5 +44,6 @@ int vvk_normalize_clips(const float* x, const long long* off, int n_clips, long 
                         hipStream_t st, const char** err);
 int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err);
 int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err);
+int vvk_rope_rows(const float* cs, const int* pos, float* out, int rows, hipStream_t st, const char** err);
 int vvk_groupnorm(const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G, float eps, int act,
                   hipStream_t st, const char** err);

@@ -50,7 +50,7 @@ class vv_gemm_args(C.Structure):
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("cos_q", C.c_void_p), ("sin_q", C.c_void_p),
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
-                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p)]
+                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32)]
 
 
 class vv_attn_args(C.Structure):
@@ -121,6 +121,7 @@ EXPORTS = {
     "vv_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                C.c_int, C.c_void_p]),
     "vv_rope_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_rope_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "vv_resample_poly": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_normalize_clips": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
