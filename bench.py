@@ -223,6 +223,9 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
+    for opt in [o for o in os.environ.get("VV_BENCH_OPTIONS", "").split(",") if o]:      # A/B switches of the C ABI, e.g. rope_rows=0
+        k, _, v = opt.partition("=")
+        eng.set_option(k, int(v))
     if os.environ.get("VV_BENCH_DUMP_MAPS"):          # diagnostics for profiler-side crashes: the loaded images, so a raw stack can be symbolised
         with open("/proc/self/maps") as src, open(os.environ["VV_BENCH_DUMP_MAPS"], "w") as dst:
             dst.write(src.read())

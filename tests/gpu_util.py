@@ -22,7 +22,7 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
 
 
 def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0, tile=0,
-         rope_pos=None):
+         rope_pos=None, rope_by_row=0):
     """A [M,K], W [N,K] on device, same dtype (bf16 or f32)."""
     dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
     od = dt if out_dtype is None else out_dtype
@@ -42,6 +42,7 @@ def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=No
             a.rope_cs_q, a.rope_cs_k = ropes[4].data_ptr(), ropes[5].data_ptr()
     a.n_store, a.seq_n, a.rope_dim, a.tile = n_store, seq_n, rope_dim, tile
     a.rope_pos = None if rope_pos is None else rope_pos.data_ptr()
+    a.rope_by_row = rope_by_row
     check(eng, eng.lib.vv_gemm(eng.ctx, C.byref(a), stream()))
     torch.cuda.synchronize()
     return C_io

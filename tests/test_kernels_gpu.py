@@ -174,6 +174,16 @@ def test_packed_rows_rope_attention_posconv(hip_tiny, dtype, tiny_setup):
     for tile in (128, 256):
         got = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=dr + cs, seq_n=N, rope_dim=Dg, tile=tile, rope_pos=pos.to(gu.DEV))
         assert gu.rel_err(got, ref) < tol, tile
+    # row-gathered compact tables (vv_rope_rows, what vv_transformer_steps builds once per call): the persistent kernel then
+    # needs no position lookup; same values gathered, so the result is bit-identical to the position-table path
+    rows = [torch.zeros(R, 64, device=gu.DEV) for _ in range(2)]
+    for i in range(2):
+        gu.check(eng, eng.lib.vv_rope_rows(eng.ctx, cs[i].data_ptr(), pos.to(gu.DEV).data_ptr(), rows[i].data_ptr(), R, gu.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(rows[0], cs[0][pos.long().to(gu.DEV)]) and torch.equal(rows[1], cs[1][pos.long().to(gu.DEV)])
+    got_rows = gu.gemm(eng, A.to(gu.DEV), W.to(gu.DEV), bias=b.to(gu.DEV), mode=1, ropes=dr + rows, seq_n=N, rope_dim=Dg, tile=256,
+                       rope_pos=pos.to(gu.DEV), rope_by_row=1)
+    assert torch.equal(got_rows, got) if dtype == torch.bfloat16 else gu.rel_err(got_rows, ref) < tol
     # --- attention over packed rows; a sentinel row after each sequence region checks nothing spills
     qkv = torch.randn(R, 3 * D, generator=g)
     qkv[:, :D] *= 0.35

@@ -25,7 +25,10 @@ pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
 cs_rows = cs[pos.long()].contiguous()            # what vv_rope_rows builds once per call
 st = torch.cuda.current_stream().cuda_stream
 tot = {p: 0.0 for p in libs}
+only = [x for x in os.environ.get("GEMM_AB_SHAPES", "").split(",") if x]      # e.g. the four shapes of one DiT block for a PMC pass
 for name, mode, N, K, act in shapes:
+    if only and name not in only:
+        continue
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
     bias = (torch.randn(N, generator=g) * 0.1).to(dev)
@@ -56,10 +59,6 @@ for name, mode, N, K, act in shapes:
                 e.lib.vv_gemm(e.ctx, C.byref(a), st)
             e1.record(); torch.cuda.synchronize()
             times[i].append(e0.elapsed_time(e1) / 10)
-    if name == "qkv_rope":
-        qkv_ref = outs[0].clone()
-    if name == "qkv_rope_rows":
-        diffs.append(("vs position-table path", float((outs[0].float() - qkv_ref.float()).abs().max())))
     line = f"{name:15s} N={N} K={K}:"
     for i, p in enumerate(libs):
         t = sorted(times[i]); med = t[len(t) // 2]

@@ -43,6 +43,9 @@ struct vv_ctx {
     size_t ar_cap = 0, ar_off = 0;
     uint64_t ws_generation = 0;         // bumped whenever ws is reallocated
     int* d_mult = nullptr;              // decode length multipliers
+    int rope_rows = 0;                  // 1: the QKV rope epilogue reads row-gathered tables (vv_rope_rows).  Off by default: 11 % faster in a
+                                        // back-to-back GEMM loop (tables stay cached), 0.9 % SLOWER inside the step, where the 52 MB of row
+                                        // tables come from HBM each time while the 0.8 MB position tables stay in L2 (profiles/r02/gemm_notes.md)
     int fuse_mrf = 2;                   // K12 fused MRF pairs (C <= 64 stages): 0 never, 1 always, 2 auto = for decodes of <= 8 items
                                         // (fewer launches win when the stage is launch-bound; at B = 32 the halo recompute costs 1.3 %)
     // profiling
@@ -430,11 +433,16 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     HIPCHK(c, hipMemcpyAsync(tab, htab.data(), sizeof(int) * htab.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));                 // htab is a local: the copy must be done before it goes away
     const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
-    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, csq_rows, csk_rows};
+    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? csq_rows : csq, c->rope_rows ? csk_rows : csk};
     KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
     KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
-    KCHK(c, vvk_rope_rows(csq, row_pos, csq_rows, (int)R, st, &m__));
-    KCHK(c, vvk_rope_rows(csk, row_pos, csk_rows, (int)R, st, &m__));
+    if (c->rope_rows) {
+        KCHK(c, vvk_rope_rows(csq, row_pos, csq_rows, (int)R, st, &m__));
+        KCHK(c, vvk_rope_rows(csk, row_pos, csk_rows, (int)R, st, &m__));
+    }
+    bool uniform = true;                                   // every sequence N rows: position = packed row mod N, no table lookup
+    for (int b = 0; b < B; ++b) uniform = uniform && hlen[b] == N;
+    const int* qkv_pos = uniform ? nullptr : row_pos;
 
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
@@ -476,7 +484,7 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, row_pos, 1)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, qkv_pos, c->rope_rows)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
                 t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
@@ -630,6 +638,7 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
+    if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
     if (!strcmp(name, "fuse_mrf")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: fuse_mrf takes 0 (off), 1 (on) or 2 (auto)");
         c->fuse_mrf = value; return 0;

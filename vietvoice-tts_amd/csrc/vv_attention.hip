@@ -45,6 +45,28 @@ __device__ __forceinline__ float half_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Workgroup -> (query block, head, sequence), XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs by linear id, and each
+// XCD has its own L2: with a plain (q-block, head, seq) grid the 13 query blocks that share one (sequence, head)'s K/V land on
+// 8 different L2s and the K/V stream is fetched from the fabric up to 8 times.  Here id % 8 labels the XCD group and every
+// group walks whole (sequence, head) pairs, query blocks consecutively, so a pair's K/V is filled into ONE L2 once and re-read
+// there by its other query blocks.  Placement is a speed matter only (any mapping is correct).
+struct AttnBlock { int qb, head, seq; bool valid; };
+__device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
+    const int b = blockIdx.x;
+#ifdef VV_ATTN_NO_XCD                                  // A/B build: the round-1 order (query blocks of a pair on consecutive ids = 8 XCDs)
+    const int pair = b / nqb, j = b;
+#else
+    const int xcd = b & 7, j = b >> 3;
+    const int pair = (j / nqb) * 8 + xcd;              // (sequence, head) pairs are dealt to the XCD groups round-robin
+#endif
+    AttnBlock r;
+    r.qb = j % nqb;
+    r.valid = pair < heads * n_seq;
+    r.head = pair % heads;
+    r.seq = pair / heads;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------ bf16
 #ifdef VV_ATTN_LB4
 #define VV_ATTN_MIN_WAVES 4
@@ -53,9 +75,11 @@ __device__ __forceinline__ float half_sum(float v) {
 #endif
 __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                           const int* __restrict__ row_start, int total_rows) {
+                                                           const int* __restrict__ row_start, int total_rows, int heads, int n_seq) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
-    const int head = blockIdx.y, seq = blockIdx.z;
+    const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
+    if (!blk.valid) return;
+    const int head = blk.head, seq = blk.seq, qblock = blk.qb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
@@ -65,14 +89,14 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
     // next sequence's, so queries stop at kv_len and every row index is clamped inside the sequence.
     const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
     const int q_lim = row_start ? kv_len : seq_n;
-    if ((int)blockIdx.x * 128 >= q_lim) return;
+    if (qblock * 128 >= q_lim) return;
 
     const bf16* Qp = qkv + row0 * ld + head * 64;
     const bf16* Kp = Qp + D;
     // bytes from Kp to the end of the qkv buffer (host-checked < 2 GiB): the bound of the K/V buffer resource
     const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
 
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblock * 128 + wave * 32;
     const int qrow = min(q0 + r32, q_lim - 1);
     bf16x8 qf[4];
 #pragma unroll
@@ -357,9 +381,11 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
 // ------------------------------------------------------------------------------------ fp32
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                          const int* __restrict__ row_start) {
+                                                          const int* __restrict__ row_start, int heads, int n_seq) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];   // per stage: K 16 KiB | V 16 KiB (256-B rows)
-    const int head = blockIdx.y, seq = blockIdx.z;
+    const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
+    if (!blk.valid) return;
+    const int head = blk.head, seq = blk.seq, qblock = blk.qb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
@@ -367,13 +393,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restric
     kv_len = max(1, min(kv_len, seq_n));
     const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;       // packed rows: see the bf16 kernel
     const int q_lim = row_start ? kv_len : seq_n;
-    if ((int)blockIdx.x * 128 >= q_lim) return;
+    if (qblock * 128 >= q_lim) return;
 
     const float* Qp = qkv + row0 * ld + head * 64;
     const float* Kp = Qp + D;
     const float* Vp = Qp + 2 * D;
 
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblock * 128 + wave * 32;
     const int qrow = min(q0 + r32, q_lim - 1);
     f32x4 qf[8];   // lane half h takes d = 8kk + 4h + j: the same k pairing as the K fragment below
 #pragma unroll
@@ -505,11 +531,16 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const int total_rows = a->total_rows > 0 ? a->total_rows : a->n_seq * a->seq_n;
     if (a->dtype == VV_BF16 && (size_t)total_rows * a->ld_qkv * 2 >= ((size_t)1 << 31)) { *err = "attention: qkv buffer must stay below 2 GiB"; return -22; }
     if (a->row_start == nullptr && total_rows < a->n_seq * a->seq_n) { *err = "attention: total_rows smaller than n_seq * seq_n"; return -22; }
-    dim3 grid((a->seq_n + 127) / 128, a->heads, a->n_seq);
+    const int nqb = (a->seq_n + 127) / 128;
+    const long long pairs8 = ((long long)a->heads * a->n_seq + 7) / 8;          // (sequence, head) pairs per XCD group
+    if (pairs8 * nqb * 8 > 0x7fffffffLL) { *err = "attention: grid too large"; return -22; }
+    const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
     if (a->dtype == VV_BF16)
-        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows);
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
+                                               a->heads, a->n_seq);
     else
-        attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start);
+        attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
+                                              a->heads, a->n_seq);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
     return 0;

@@ -50,6 +50,7 @@ struct EpiArgs {
     int n_store;
     int seq_n;
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
+    unsigned seq_rcp;        // ceil(2^32 / seq_n): row -> position without a table when every sequence has seq_n rows (m * seq_n < 2^32)
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
 #ifdef VV_GEMM_ABLATE
@@ -593,7 +594,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     if constexpr (MODE == MODE_QKV_ROPE) {
                         const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim;
                         do_rope = rope_tile && e.cs_q != nullptr;
-                        if (rope_tile) pos = e.cs_by_row ? min(m, M - 1) : (e.pos_tab ? e.pos_tab[min(m, M - 1)] : min(m, M - 1) % e.seq_n);
+                        if (rope_tile) {
+                            const int mc = min(m, M - 1);
+                            if (e.cs_by_row) pos = mc;
+                            else if (e.pos_tab) pos = e.pos_tab[mc];
+                            else {                                     // uniform sequences: m mod seq_n by reciprocal multiply, no load
+                                pos = mc - (int)__umulhi((unsigned)mc, e.seq_rcp) * e.seq_n;
+                                if (pos >= e.seq_n) pos -= e.seq_n;
+                            }
+                        }
                         if (do_rope) {
                             const float* tab = (bn + wc * 64 >= e.rope_dim ? e.cs_k : e.cs_q) + (size_t)pos * 64;
 #pragma unroll
@@ -637,7 +646,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                 for (int q = 0; q < 4; ++q) {
                     const int lr = q * 8 + (lane >> 3);
                     const int ch = lane & 7;
+#ifdef VV_GEMM_G2
+                    // hipcc drains vmcnt(0) before a ds_read that follows LDS-DMA in flight (it cannot prove the DMA targets another
+                    // region): the ring's prefetch for the next tile would be waited for at every epilogue.  An asm read-back is not
+                    // part of that bookkeeping; its own lgkmcnt wait sits in the same statement (cdna guide 5.7 item 1, form i).
+                    uint4 val;
+                    {
+                        const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
+                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(val) : "v"(la) : "memory");
+                    }
+#else
                     const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
+#endif
                     const int m = bm + g * 128 + ps * 32 + lr;
                     const int n0 = bn + wc * 64 + ch * 8;
 #ifdef VV_GEMM_G1
@@ -788,6 +808,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
+    e.seq_rcp = (unsigned)((((unsigned long long)1 << 32) + (unsigned)e.seq_n - 1) / (unsigned)e.seq_n);
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
 #ifdef VV_GEMM_ABLATE
     {   // ablation build only (never the shipped library): bits from the environment, read once per process
@@ -795,6 +816,9 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         e.dbg = dbg_env;
     }
 #endif
+    if (g->mode == MODE_QKV_ROPE && !g->rope_pos && (unsigned long long)g->M * (unsigned long long)e.seq_n >= ((unsigned long long)1 << 32)) {
+        *err = "gemm: rope without a position table needs M * seq_n < 2^32"; return -22;
+    }
     if (g->mode == MODE_QKV_ROPE && (!g->cos_q || !g->sin_q || !g->cos_k || !g->sin_k || g->rope_dim % 64)) {
         *err = "gemm: rope epilogue needs the four tables and rope_dim % 64 == 0"; return -22;
     }
