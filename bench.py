@@ -299,10 +299,11 @@ def main():
     peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so the figure comes from the committed
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command (tools/pmc_traffic.py -> profiles/<round>/bench_pmc_traffic.json)
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py).  Passes over THIS command die inside the profiler
+    # (profiles/r02/gemm_notes.md, stack + maps committed), so the r02 file is taken over tools/gemm_ab.py at the block's four shapes.
     traffic, traffic_src = None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for rel in ("profiles/r02/bench_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
+    for rel in ("profiles/r02/bench_pmc_traffic.json", "profiles/r02/gemm_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
         tf = os.path.join(here, rel)
         if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
             with open(tf) as fh:
