@@ -24,6 +24,10 @@
 #if !defined(VV_GEMM_NO_G1) && !defined(VV_GEMM_ABLATE)
 #define VV_GEMM_G1 1
 #endif
+// E2 (round 2): both wave groups run their epilogue in the same barrier interval; -3.2 % on the four block shapes, bit-identical.
+#if !defined(VV_GEMM_NO_E2)
+#define VV_GEMM_E2 1
+#endif
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // vector load sits at the top of a tile or in the epilogue any more (its in-order vmcnt wait drained the 16 stores).
     constexpr bool G1 = sizeof(To) == 2 && MODE != MODE_GATE_RES;
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
+    const unsigned st_lane = ((unsigned)(lane >> 3) * (unsigned)ldc + (unsigned)(lane & 7) * 8u) * 2u;     // store: row lane>>3, 16-byte chunk lane&7
     auto lane_get = [&](float v, int src_lane) {
         return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
     };
@@ -422,6 +427,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
+#ifdef VV_GEMM_ABLATE
+        if (e.dbg & 2048) {          // timing only: the cluster twice (32 MFMAs per barrier interval, same loads / reads / barriers)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
+        }
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -466,11 +482,47 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         bar(); cluster(1, 0); bar();
     };
 
+#ifdef VV_GEMM_P2
+    // P2: TWO barrier intervals per K-tile half instead of four -- each C segment is 32 MFMAs (two quadrants), so the ~65 cycles
+    // an interval loses around its barriers (measured: doubling the MFMAs per interval adds exactly their pipe time) are paid 4x
+    // per K-tile, not 8x.
+    //   PA(T): read Wn0, Wn1, Am0 of T | stage Wn0, Wn1, Am0 of T+1 | quadrants (m0,n0) (m0,n1)
+    //   PB(T): read Am1 of T            | stage Am1 of T+1           | quadrants (m1,n1) (m1,n0)
+    // A slot is restaged three intervals after this group read it (the other group reads one interval later and has its data
+    // in registers by the end of its own C segment); data is read two barriers after the staging wave's counted wait.
+    // Prefetch distance: one K-tile.  Counted waits: end of L(PA) needs Am1(T) (staged PB(T-1)): vmcnt(6); end of L(PB) needs
+    // the PA set of T+1: vmcnt(2).  The FIRST K-tile of a tile stages nothing in PA (its T+1 set was staged at the start of
+    // the previous tile's epilogue, ahead of the 16 output stores, or in the prologue): with G1's counted stores its waits are
+    // vmcnt(6 + 16) and vmcnt(2 + 16), so the stores stay in flight for the whole first K-tile.
+    auto ktile2 = [&](auto first_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n) {
+        constexpr bool first = decltype(first_c)::value;
+        const char* base = smem + par * (4 * UNIT);
+        const bool r1 = T + 1 >= nk;
+        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? T + 1 - nk : T + 1;
+        // ---- PA
+        read_w(0, base + 0 * UNIT);
+        read_w(1, base + 2 * UNIT);
+        read_a(base + 1 * UNIT);
+        if constexpr (!first) { stage(T0{}, bm1, bn1, t1, par ^ 1); stage(T2{}, bm1, bn1, t1, par ^ 1); stage(T1{}, bm1, bn1, t1, par ^ 1); }
+        if constexpr (first && G1) VV_WAITVM(22); else VV_WAITVM(6);
+        bar(); cluster(0, 0); cluster(0, 1); bar();
+        // ---- PB
+        read_a(base + 3 * UNIT);
+        stage(T3{}, bm1, bn1, t1, par ^ 1);
+        if constexpr (first && G1) VV_WAITVM(18); else VV_WAITVM(2);
+        bar(); cluster(1, 1); cluster(1, 0); bar();
+    };
+#endif
+
     // prologue = phases -6..-1 of the staging schedule for this block's first tile
     {
         const int bm0 = tile_bm(0), bn0 = tile_bn(0);
         stage(T0{}, bm0, bn0, 0, 0); stage(T1{}, bm0, bn0, 0, 0); stage(T2{}, bm0, bn0, 0, 0); stage(T3{}, bm0, bn0, 0, 0);
+#ifdef VV_GEMM_P2
+        stage(T0{}, bm0, bn0, 1, 1); stage(T2{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);      // the PA set of K-tile 1
+#else
         stage(T0{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);
+#endif
     }
 #ifdef VV_GEMM_G1
     float bias_nx = 0.f, gate_nx = 0.f;
@@ -484,7 +536,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         if constexpr (MODE == MODE_GATE_STORE) gate_nx = e.gate[tile_bn(0) + wc * 64 + lane];
     }
 #endif
+#ifdef VV_GEMM_P2
+    VV_WAITVM(6);                                              // K-tile 0 complete (at most the K-tile 1 set still in flight)
+#else
     VV_WAITVM(8);
+#endif
     bar();
     if (g == 1) bar();                                         // stagger group 1 by one segment
 
@@ -518,6 +574,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // first K-tile after a full bf16 tile store (every wave issued exactly 16 stores): leave those stores in flight
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
+#ifdef VV_GEMM_P2
+        ktile2(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
+        ++G;
+        for (int T = 1; T < nk; ++T, ++G) ktile2(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n);
+        // the PA set of the NEXT tile's K-tile 1: its slots (the parity of the K-tile just finished) were last read three
+        // intervals ago; issued here, ahead of the 16 stores, it is older than them for the first K-tile's counted waits
+        stage(T0{}, bm_n, bn_n, 1, (G & 1) ^ 1); stage(T2{}, bm_n, bn_n, 1, (G & 1) ^ 1); stage(T1{}, bm_n, bn_n, 1, (G & 1) ^ 1);
+#else
         if constexpr (G1) {
             ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);             // 16 stores (real or dropped) always precede a tile
         } else if constexpr (MODE == MODE_STORE) {
@@ -528,8 +592,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         }
         ++G;
         for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n);
+#endif
         stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && !VV_DBG(e) && bm + 256 <= M && bn + 256 <= e.n_store;
 
+#ifdef VV_GEMM_E2
+        // E2: both groups run their epilogue in the SAME barrier interval.  With the plain one-segment stagger, group 0's epilogue
+        // overlaps only group 1's last MFMA cluster and group 1's epilogue only group 0's first cluster of the next tile: the two
+        // ~3 us epilogues of a tile run back to back with the matrix pipe idle.  Group 0 therefore waits out one interval here
+        // (group 1 is in its last cluster), and group 1 re-establishes the stagger with one barrier after its epilogue.
+        if (g == 0) bar();
+#endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
             const float k1 = e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f;
@@ -637,7 +709,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                                 }
                             }
                             const int chunk = (nl >> 3) ^ (lr & 7);
-                            bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            const bf16x4 pk = __builtin_convertvector(v, bf16x4);       // 2 x v_cvt_pk_bf16_f32 (element-wise casts cost 5 instructions)
                             *(bf16x4*)(stg + lr * 128 + chunk * 16 + (nl & 4) * 2) = pk;
                         }
                 }
@@ -664,8 +736,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     if constexpr (G1) {
                         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
                         const u32x4 vv = {val.x, val.y, val.z, val.w};
-                        const unsigned off = (m < M && n0 < e.n_store) ? ((unsigned)m * (unsigned)ldc + (unsigned)n0) * 2u : 0x7ffffff0u;
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)off, 0, 2);       // nt; out-of-range lanes are dropped by the resource bound
+                        // per-lane part of the address once per kernel (st_lane), the tile / pass / row-group part as the SCALAR offset of
+                        // the instruction; validity is decided on the vector offset (the scalar one is not range-checked)
+                        const int row_first = bm + g * 128 + ps * 32 + q * 8;                  // wave-uniform
+                        const bool ok = (lane >> 3) < M - row_first && n0 < e.n_store;
+                        const unsigned soff = ((unsigned)row_first * (unsigned)ldc + (unsigned)(bn + wc * 64)) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
                     } else
 #endif
                     if (m < M && n0 < e.n_store && !(VV_DBG(e) & 128)) {
@@ -713,6 +789,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         }
                 }
         }
+#ifdef VV_GEMM_E2
+        if (g == 1) bar();                                     // group 1 falls one segment behind again
+#endif
     }
     if (g == 0) bar();                                         // balance group 1's extra barrier
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
