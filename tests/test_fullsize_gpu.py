@@ -208,3 +208,51 @@ def test_bf16_full_size_close_to_oracle_and_b32_properties(full_case):
     # items differ (different clips / ids / noise): the batch is not one utterance repeated
     assert float((x32[1] - x32[0]).abs().max()) > 1e-2
     eng.close()
+
+
+def test_fp32_full_size_ragged_batch_matches_oracle(full_case):
+    """configs[3] semantics at FULL model size: a ragged batch (three utterances of different reference-clip, text and frame
+    lengths, packed rows, per-item masks in attention / pos-conv / text conv, bucketed vocoder) through the fp32 path, one Euler
+    step over the whole interval, every item against the fp32 oracle run on that item alone.  Tolerance as derived in the module
+    docstring: state rmse/rms <= 1e-4 (fp32 floor measured 1.3e-5 for one step), max error <= 1e-3 of the state range, PCM +-1 LSB
+    on >= 99.9 % of the samples (two fp32 implementations are compared here, each ~1e-5 from float64)."""
+    import bench
+    from vietvoice_tts_amd.runtime import HipSynth
+    from oracle.vv_oracle import Oracle
+    c = full_case
+    spec = c["spec"]
+    g = torch.Generator().manual_seed(77)
+    la, lt, gf = [144000, 256 * 330 + 100, 256 * 150], [256, 140, 64], [1037, 520, 260]
+    B = len(la)
+    audio = torch.zeros(B, max(la), dtype=torch.int16)
+    ids = torch.zeros(B, max(lt), dtype=torch.int32)
+    for b in range(B):
+        audio[b, : la[b]] = bench.synth_reference_clip(100 + b, la[b])
+        ids[b, : lt[b]] = torch.randint(1, spec.vocab_size, (lt[b],), generator=g, dtype=torch.int32)
+    seq = [la[b] // spec.hop_length + 1 + gf[b] for b in range(B)]
+    N = max(seq)
+    noise = torch.randn(B, N, spec.n_mel, generator=g)
+    orc = Oracle(spec, c["w"], nfe_step=2)               # one Euler step, dt = 1
+    eng = HipSynth(spec, c["w"], acoustic_dtype="fp32", nfe_step=2)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    pre = eng.preprocess(audio.to(DEV), i32(la), ids.to(DEV), i32(lt), i32(seq), N)
+    x = noise.to(DEV).clone()
+    eng.transformer_steps(x, pre, 0, 1)
+    pcm, pcm_len = eng.decode_bucketed(x, pre, gf, pad_frac=0.10, min_units=1)
+    torch.cuda.synchronize()
+    for b in range(B):
+        with torch.no_grad():
+            p = orc.preprocess(audio[b, : la[b]], ids[b, : lt[b]], seq[b], noise[b, : seq[b]])
+            xr = orc.transformer_step(p["noise"], p, 0)
+            pr = orc.to_pcm(orc.vocoder(xr[p["ref_signal_len"]:]))
+        got = x[b, : seq[b]].cpu()
+        err = (got - xr).abs()
+        rm = float(err.pow(2).mean().sqrt() / xr.pow(2).mean().sqrt())
+        n = pr.numel()
+        d = (pcm[b, :n].cpu().int() - pr.int()).abs()
+        print(f"\n[full fp32 ragged] item {b} (N={seq[b]}, T={lt[b]}, gen={gf[b]}): state rmse/rms {rm:.2e}, max {float(err.max()):.2e} of range "
+              f"{float(xr.abs().max()):.1f}; PCM max diff {int(d.max())} LSB on {int((d > 0).sum())} of {n}")
+        assert int(pre["ref_signal_len"][b]) == p["ref_signal_len"] and int(pcm_len[b]) == n == gf[b] * spec.hop_length
+        assert rm <= 1e-4 and float(err.max()) <= 1e-3 * float(xr.abs().max())
+        assert int(d.max()) <= 2 and float((d > 1).float().mean()) < 1e-3
+    eng.close()
