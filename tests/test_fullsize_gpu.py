@@ -250,7 +250,9 @@ def test_fp32_full_size_ragged_batch_matches_oracle(full_case):
         rm = float(err.pow(2).mean().sqrt() / xr.pow(2).mean().sqrt())
         n = pr.numel()
         d = (pcm[b, :n].cpu().int() - pr.int()).abs()
-        print(f"\n[full fp32 ragged] item {b} (N={seq[b]}, T={lt[b]}, gen={gf[b]}): state rmse/rms {rm:.2e}, max {float(err.max()):.2e} of range "
+        fr, mb = divmod(int(err.argmax()), spec.n_mel)
+        print(f"\n[full fp32 ragged] item {b} (N={seq[b]}, T={lt[b]}, gen={gf[b]}): state rmse/rms {rm:.2e}, max {float(err.max()):.2e} (frame {fr} of "
+              f"{seq[b]}, ref frames {p['ref_signal_len']}, bin {mb}; p99.9 {float(err.flatten().kthvalue(int(err.numel() * 0.999)).values):.2e}) of range "
               f"{float(xr.abs().max()):.1f}; PCM max diff {int(d.max())} LSB on {int((d > 0).sum())} of {n}")
         assert int(pre["ref_signal_len"][b]) == p["ref_signal_len"] and int(pcm_len[b]) == n == gf[b] * spec.hop_length
         assert rm <= 1e-4 and float(err.max()) <= 1e-3 * float(xr.abs().max())
