@@ -25,7 +25,7 @@
 #define VV_GEMM_G1 1
 #endif
 // E2 (round 2): both wave groups run their epilogue in the same barrier interval; -3.2 % on the four block shapes, bit-identical.
-#if !defined(VV_GEMM_NO_E2)
+#if !defined(VV_GEMM_NO_E2) && !defined(VV_GEMM_ABLATE)
 #define VV_GEMM_E2 1
 #endif
 #include <atomic>
@@ -600,12 +600,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // overlaps only group 1's last MFMA cluster and group 1's epilogue only group 0's first cluster of the next tile: the two
         // ~3 us epilogues of a tile run back to back with the matrix pipe idle.  Group 0 therefore waits out one interval here
         // (group 1 is in its last cluster), and group 1 re-establishes the stagger with one barrier after its epilogue.
+        // (Letting group 0 run its pre-pass and first store pass inside that interval instead of idling was measured: QKV +1.4 %,
+        // the rest flat -- profiles/r02/gemm_notes.md.)
         if (g == 0) bar();
 #endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
-            const float k1 = e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f;
-            const float k3 = e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f;
+            // x * sigmoid(2u) == 0.5 x (1 + tanh u);  sigmoid(w) = 1 / (1 + 2^(-w log2 e)): the -log2(e) is folded into the constants
+            const float k1 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f);
+            const float k3 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float xv = acc[mh][nh][mi][ni][j];
-                                acc[mh][nh][mi][ni][j] = xv * fast_sigmoid(xv * (k1 + k3 * xv * xv));   // x * sigmoid(2u) == 0.5 x (1 + tanh u)
+                                acc[mh][nh][mi][ni][j] = xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * (k1 + k3 * xv * xv)));
                             }
         }
         if constexpr (MODE == MODE_GATE_STORE) {
