@@ -370,6 +370,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     unsigned voff_w[2][2];     // [n-half][piece]  relative to the tile's first weight row
     int loc_a[2];              // [piece]          token row of the piece inside the tile (m-half 0); + 64 for m-half 1
     unsigned cbyte[2];
+#ifndef VV_GEMM_NO_A1
+    unsigned voff_a[2][2];     // [m-half][piece]  per-lane byte offset of the piece's token row inside the tile (A1, below)
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int ur = (wave * 2 + u) * 8 + (lane >> 3);              // row inside the unit
@@ -377,6 +380,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         loc_a[u] = (ur >> 6) * 128 + (ur & 63);
 #pragma unroll
         for (int h = 0; h < 2; ++h) voff_w[h][u] = (unsigned)((ur >> 5) * 64 + h * 32 + (ur & 31)) * (unsigned)ldw * 2u + cbyte[u];
+#ifndef VV_GEMM_NO_A1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) voff_a[h][u] = (unsigned)(loc_a[u] + h * 64) * (unsigned)lda * 2u + cbyte[u];
+#endif
     }
     // stage unit `type` of K-tile Tk (parity par) of the tile whose origin is (bmS, bnS)
     auto stage = [&](auto type_c, int bmS, int bnS, int Tk, int par) {
@@ -386,7 +393,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if constexpr (type & 1) {
+#ifndef VV_GEMM_NO_A1
+                // A1: one v_add per piece (tile origin is a scalar) instead of add + clamp + 64-bit multiply in every phase.  Rows past
+                // M need no clamp: their offset is past the resource's num_records (the origin is part of the VECTOR offset, the
+                // part the hardware range-checks), so the DMA writes zeros; those rows are computed but never stored.
+                const unsigned v = voff_a[h][u] + (unsigned)bmS * (unsigned)lda * 2u;
+#else
                 const unsigned v = (unsigned)min(bmS + loc_a[u] + h * 64, M - 1) * (unsigned)lda * 2u + cbyte[u];   // clamp: rows >= M never stored
+#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(slot + u * 1024), 16, (int)v, Tk * 128, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(slot + u * 1024), 16, (int)voff_w[h][u], bnS * ldw * 2 + Tk * 128, 0, 0);
