@@ -7,6 +7,32 @@ from vietvoice_tts_amd import runtime as rt
 from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 spec = ModelSpec.full()
+# A/B of whole libraries in one process: VOC_AB_LIBS=libA.so,libB.so (interleaved rounds, fuse_mrf fixed to 0)
+ab = [p for p in os.environ.get("VOC_AB_LIBS", "").split(",") if p]
+if ab:
+    w = make_synthetic_weights(spec)
+    engs = []
+    for p in ab:
+        rt._lib = None
+        rt._lib = rt.load_library(p)
+        e = rt.HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4)
+        e.set_option("fuse_mrf", 0)
+        engs.append(e)
+    dev = "cuda:0"
+    B, N, ref = 32, 1600, 563
+    x = torch.randn(B, N, spec.n_mel, generator=torch.Generator().manual_seed(0)).to(dev)
+    pre = {"ref_signal_len": torch.full((B,), ref, dtype=torch.int32, device=dev), "seq_len": torch.full((B,), N, dtype=torch.int32, device=dev)}
+    outs = [e.decode(x, pre, N - ref)[0].clone() for e in engs]
+    print("PCM identical across libraries:", all(torch.equal(o, outs[0]) for o in outs))
+    for r in range(3):
+        for p, e in zip(ab, engs):
+            e.prof_enable(True)
+            for _ in range(iters):
+                e.decode(x, pre, N - ref)
+            pr = e.prof_collect()["voc_conv"]
+            e.prof_enable(False)
+            print(f"{os.path.basename(p):28s} conv class {pr['ms'] / iters:.2f} ms  {pr['flops'] / (pr['ms'] * 1e-3) / 1e12:.1f} TFLOP/s f32", flush=True)
+    sys.exit(0)
 eng = rt.HipSynth(spec, make_synthetic_weights(spec), acoustic_dtype="bf16", nfe_step=4)
 dev = "cuda:0"
 B, N, ref = 32, 1600, 563

@@ -19,7 +19,16 @@ namespace {
 
 constexpr int VT = 256;       // time steps per workgroup
 
+// LeakyReLU for 0 < slope <= 1 (host-checked): max(x, slope * x) -- the same values as x >= 0 ? x : slope * x bit for bit
+// (-0 and NaN included), in two instructions instead of three.  Staging arithmetic is issued from the same SIMD port as
+// the MFMAs of the co-resident workgroups, so every instruction here is paid for by the matrix pipe.
+#ifdef VV_VOC_NO_DIET          // A/B build: round-1 staging (3-instruction LeakyReLU, per-element range logic everywhere)
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
+#define VV_VOC_INTERIOR(expr) false
+#else
+__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }
+#define VV_VOC_INTERIOR(expr) (expr)
+#endif
 
 // KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).  VCI: input channels per K chunk.
 // RT: 32-row MFMA tiles per wave (2 -> 64 rows per workgroup, 1 -> 32 rows for the narrow last stage).
@@ -69,6 +78,18 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
         __syncthreads();
         // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 - L4 + i]), zero outside [0, lin); wave w takes
         // channels w, w+4, ...; aligned float4 loads wherever the four samples are inside the row
+        // interior workgroups (window inside [0, len), aligned rows, whole chunk live): no per-element range logic at all
+        const bool interior = VV_VOC_INTERIOR(vec_ok && q0 - L4 >= 0 && q0 - L4 + xw_pad <= lin && c0 + VCI <= Cin);
+        if (interior) {
+            for (int c = wave; c < VCI; c += 4) {
+                const float* row = inb + (size_t)(c0 + c) * T_in + (q0 - L4);
+                for (int i4 = lane; i4 < xw4; i4 += 64) {
+                    float4 v = *(const float4*)(row + i4 * 4);
+                    v.x = lrelu(v.x, pre_slope); v.y = lrelu(v.y, pre_slope); v.z = lrelu(v.z, pre_slope); v.w = lrelu(v.w, pre_slope);
+                    *(float4*)(xs + c * xw_pad + i4 * 4) = v;
+                }
+            }
+        } else
         for (int c = wave; c < VCI; c += 4) {
             const bool live = c0 + c < Cin;
             const float* row = inb + (size_t)(c0 + c) * T_in;
@@ -205,6 +226,17 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
     zero_acc();
     for (int c0 = 0; c0 < C; c0 += VCI) {
         __syncthreads();
+        const bool interior = VV_VOC_INTERIOR(vec_ok && q0 - A >= 0 && q0 - A + xw_pad <= lin);          // no per-element range logic (see conv_mfma_kernel)
+        if (interior) {
+            for (int c = wave; c < VCI; c += 4) {
+                const float* row = yb + (size_t)(c0 + c) * T + (q0 - A);
+                for (int i4 = lane; i4 < xw4; i4 += 64) {
+                    float4 v = *(const float4*)(row + i4 * 4);
+                    v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
+                    *(float4*)(xs + c * xw_pad + i4 * 4) = v;
+                }
+            }
+        } else
         for (int c = wave; c < VCI; c += 4) {
             const float* row = yb + (size_t)(c0 + c) * T;
             for (int i4 = lane; i4 < xw4; i4 += 64) {
@@ -432,6 +464,7 @@ int launch_conv(const vv_conv_args* a, hipStream_t st) {
 
 int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->T_in <= 0 || a->T_out <= 0) { *err = "conv: empty shape"; return -22; }
+    if (!(a->pre_slope > 0.f && a->pre_slope <= 1.f)) { *err = "conv: pre_slope must be in (0, 1] (1 = no activation)"; return -22; }
     if (a->rows_pad % 64 || a->rows_pad < a->rows_total || ((uintptr_t)a->W % 16)) { *err = "conv: weight slab must be padded to 64 rows and 16-byte aligned"; return -22; }
     if (a->transposed) {
         if (a->KW != 2 || a->up < 2 || (a->up & 1) || a->rows_total != a->Cout * a->up || a->T_out != a->T_in * a->up) {
@@ -470,6 +503,7 @@ int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
     if (a->B <= 0 || a->T <= 0 || (a->C != 32 && a->C != 64)) { *err = "mrf_resblock: fused form needs C = 32 or 64 (the intermediate tile must fit the CU)"; return -22; }
     if (a->rows_pad != 64 || ((uintptr_t)a->W1 % 16) || ((uintptr_t)a->W2 % 16)) { *err = "mrf_resblock: weight slabs [C_pad8][KW][64], 16-byte aligned"; return -22; }
     if (a->dil < 1 || a->dil > 5) { *err = "mrf_resblock: dilation 1..5"; return -22; }
+    if (!(a->slope > 0.f && a->slope <= 1.f)) { *err = "mrf_resblock: slope must be in (0, 1]"; return -22; }
     if (a->out == a->y) { *err = "mrf_resblock: out must not alias y (neighbouring workgroups read y's halo)"; return -22; }
     const bool wide = a->C == 64;
     switch (a->KW) {
@@ -488,6 +522,7 @@ int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
 int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T, int KW,
                   float pre_slope, const int* len_in, hipStream_t st, const char** err) {
     if (KW != 7 || C > 64 || C < 1) { *err = "conv_post: k=7 and C<=64 expected"; return -22; }
+    if (!(pre_slope > 0.f && pre_slope <= 1.f)) { *err = "conv_post: pre_slope must be in (0, 1]"; return -22; }
     const size_t lds = (size_t)(8 * (1024 + 8) + C * 7) * sizeof(float);
     dim3 grid((T + 1023) / 1024, B);
     conv_post_kernel<7><<<grid, 256, lds, st>>>(in, w, bias, pcm, ld_pcm, wave_f32, C, T, pre_slope, len_in);
