@@ -19,15 +19,15 @@ namespace {
 
 constexpr int VT = 256;       // time steps per workgroup
 
-// LeakyReLU for 0 < slope <= 1 (host-checked): max(x, slope * x) -- the same values as x >= 0 ? x : slope * x bit for bit
-// (-0 and NaN included), in two instructions instead of three.  Staging arithmetic is issued from the same SIMD port as
-// the MFMAs of the co-resident workgroups, so every instruction here is paid for by the matrix pipe.
-#ifdef VV_VOC_NO_DIET          // A/B build: round-1 staging (3-instruction LeakyReLU, per-element range logic everywhere)
+// LeakyReLU.  -DVV_VOC_DIET builds the round-2 experiment (max(x, slope x) in two instructions + an interior fast path without
+// per-element range logic in the staging loops): bit-identical PCM, but the conv class got SLOWER at the headline batch, 191.1 ->
+// 204.0 ms (profiles/r02/vocoder_notes.md), so the round-1 staging stays the default.
+#ifdef VV_VOC_DIET
+__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }     // needs 0 < slope <= 1 (host-checked)
+#define VV_VOC_INTERIOR(expr) (expr)
+#else
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
 #define VV_VOC_INTERIOR(expr) false
-#else
-__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }
-#define VV_VOC_INTERIOR(expr) (expr)
 #endif
 
 // KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).  VCI: input channels per K chunk.
