@@ -66,6 +66,7 @@ def make_inputs(spec: ModelSpec, B: int, rank: int, device):
              seq_len=torch.full((B,), N, dtype=torch.int32, device=device), noise=noise.to(device))
     if torch.device(device).type == "cuda":          # host-side originals (pinned) for the H2D leg of the timed step
         d["host"] = {k: t.pin_memory() for k, t in (("audio", audio), ("ids", ids), ("noise", noise))}
+    d["seq_len_host"] = [N] * B                        # the caller knows the frame counts: no read-back inside the Euler-step call
     return d, N
 
 
@@ -99,6 +100,7 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
         d = dict(audio=audio.to(device), audio_len=samples[units].to(torch.int32).to(device), ids=ids.to(device),
                  text_len=toks[units].to(torch.int32).to(device), seq_len=seq.to(device), noise=noise.to(device))
         d["host"] = {k: t.pin_memory() for k, t in (("audio", audio), ("ids", ids), ("noise", noise))}
+        d["seq_len_host"] = [int(v) for v in seq]
         d["gen_frames"] = [int(gen_frames[u]) for u in units]
         batches.append((d, N, int(gen_frames[units].max())))
     audio_s = float(gen_frames[mine].sum()) * spec.hop_length / spec.sample_rate
@@ -245,7 +247,8 @@ def main():
                 audio, ids, noise = (d["host"][k].to(device, non_blocking=True) for k in ("audio", "ids", "noise"))
             else:
                 audio, ids, noise = d["audio"], d["ids"], d["noise"]
-            o = eng.synthesize_batch(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, noise, t_gen, gen_frames=d.get("gen_frames"))
+            o = eng.synthesize_batch(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, noise, t_gen, gen_frames=d.get("gen_frames"),
+                                     seq_len_host=d.get("seq_len_host"))
             if pcie:
                 if pcm_host[i] is None:
                     pcm_host[i] = (torch.empty(o[1].shape, dtype=o[1].dtype).pin_memory(), torch.empty(o[2].shape, dtype=o[2].dtype).pin_memory())

@@ -89,6 +89,13 @@ int vv_transformer_steps(vv_ctx* ctx, int B, int N, const int32_t* seq_len, floa
                          const float* cat_mel_text_drop, const float* rope_cos_q, const float* rope_sin_q,
                          const float* rope_cos_k, const float* rope_sin_k, int step0, int n_steps, void* stream);
 
+/* The same call with the per-item lengths also handed over on the HOST (same values as the device array): the host needs them
+ * for the launch shapes, so vv_transformer_steps reads them back (one 4*B-byte copy + stream synchronisation per call); this form
+ * has no synchronisation at all and can be captured into a hipGraph once the context arena is large enough. */
+int vv_transformer_steps_h(vv_ctx* ctx, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x,
+                           const float* cat_mel_text, const float* cat_mel_text_drop, const float* rope_cos_q, const float* rope_sin_q,
+                           const float* rope_cos_k, const float* rope_sin_k, int step0, int n_steps, void* stream);
+
 /* replaces sessions['decode'].run, core/tts_engine.py:176-187: frames [ref_len, seq_len) of x ->
  * vocoder -> int16 PCM.  pcm [B][ld_pcm], ld_pcm >= t_gen_max*hop; pcm_len[B] = samples per item.
  * wave_f32 (optional, [B][t_gen_max*hop]) receives the pre-quantisation waveform. */

@@ -119,6 +119,34 @@ def test_step_splitting_is_exact(hip_tiny, tiny_setup):
     assert torch.equal(x1, x2)
 
 
+def test_host_lengths_form_is_identical_and_graph_capturable(hip_tiny, tiny_setup):
+    """vv_transformer_steps_h (lengths also given on the host): no read-back and no stream synchronisation inside the call, the
+    packed-row tables are built on the device.  Same state bit for bit as the read-back form, on a ragged batch; and with the
+    context arena already sized the whole Euler-step loop can be captured into a hipGraph and replayed."""
+    spec, _, _ = tiny_setup
+    eng = hip_tiny["f32"]
+    batch = make_batch(spec, [256 * 20, 256 * 12 + 100, 256 * 30], [30, 11, 47], [24, 9, 40], seed=19)
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"])
+    x_dev = d["noise"].clone()
+    eng.transformer_steps(x_dev, pre, 0, 5)                                   # lengths read back from the device
+    lens = [int(v) for v in batch["seq_len"]]
+    x_host = d["noise"].clone()
+    eng.transformer_steps(x_host, pre, 0, 5, seq_len_host=lens)               # lengths from the host: sync-free
+    torch.cuda.synchronize()
+    assert torch.equal(x_dev, x_host)
+    x_g = d["noise"].clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.transformer_steps(x_g, pre, 0, 5, seq_len_host=lens)
+    x_g.copy_(d["noise"])
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x_g, x_dev)
+    with pytest.raises(RuntimeError, match="seq_len"):                        # host lengths are validated like device lengths
+        eng.transformer_steps(d["noise"].clone(), pre, 0, 1, seq_len_host=[lens[0], 0, lens[2]])
+
+
 def test_batch_equals_singles(hip_tiny, tiny_setup):
     """Batched ragged synthesis must equal each utterance synthesised alone (key-padding / edge masks)."""
     spec, _, _ = tiny_setup

@@ -71,7 +71,7 @@ def full_case():
 
 
 def _dev(d, sl):
-    return {k: v[sl].contiguous().to(DEV) for k, v in d.items()}
+    return {k: v[sl].contiguous().to(DEV) for k, v in d.items() if torch.is_tensor(v)}
 
 
 def _run(eng, d, N, gen, n_steps=N_STEPS, want_wave=True):

@@ -196,7 +196,7 @@ class TTSEngine:
                 noise[i, : seq[i]] = noise_blocks[j]
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
             if self.config.use_hip_graph:
-                pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N)
+                pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, seq_len_host=seq)
                 x = noise.to(dev)
                 eng.transformer_steps(x, pre, 0, eng.n_steps)
                 key = (B, N, t_gen)
@@ -205,7 +205,7 @@ class TTSEngine:
                 pcm, pcm_len = self._decode_graphs[key](x, pre["ref_signal_len"], pre["seq_len"])
             else:
                 _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen,
-                                                              gen_frames=[int(v) for v in (seq - ref_frames)])
+                                                              gen_frames=[int(v) for v in (seq - ref_frames)], seq_len_host=seq)
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
             for i, j in enumerate(idx):
                 waves[j] = pcm[i, : pcm_len[i]].reshape(1, 1, -1)

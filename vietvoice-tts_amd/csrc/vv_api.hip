@@ -370,9 +370,9 @@ int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, i
 }
 
 // --------------------------------------------------------------------------- transformer steps
-int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float* x, const float* cat, const float* cat_drop,
-                         const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
-                         int step0, int n_steps, void* stream) {
+static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x, const float* cat,
+                                  const float* cat_drop, const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k,
+                                  const float* rope_sin_k, int step0, int n_steps, void* stream) {
     if (!c) return -22;
     if (!c->finalized || !c->modtab) return c->fail(-1, "vv_transformer_steps: weights/time grid not ready");
     if (B < 1 || N < 1 || !seq_len || !x || !cat || !cat_drop || !rope_cos_q || !rope_sin_q || !rope_cos_k || !rope_sin_k)
@@ -386,10 +386,16 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     if ((size_t)2 * B * N > (size_t)1 << 30) return c->fail(-22, "batch too large");
     // Ragged rows are PACKED: sequence (branch, b) owns rows [row_start, +len_b) of every activation buffer, the conditional
     // branch first, so GEMMs / norms / convs touch sum(len) rows instead of B x N_max.  The host needs the row count for the
-    // launch shapes: one 4*B-byte read-back per call.  x, cat and cat_drop keep their padded [B][N] layout (row_src maps).
+    // launch shapes: the caller hands the lengths over on the host as well (vv_transformer_steps_h: no synchronisation at all,
+    // the call can be captured into a hipGraph), or they are read back once (4*B bytes, one stream synchronisation).  The row
+    // tables themselves are built on the device.  x, cat and cat_drop keep their padded [B][N] layout (row_src maps).
     std::vector<int> hlen(B);
-    HIPCHK(c, hipMemcpyAsync(hlen.data(), seq_len, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (seq_len_host) {
+        std::copy(seq_len_host, seq_len_host + B, hlen.begin());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(hlen.data(), seq_len, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     size_t Rc = 0;
     double sum_sq = 0;
     for (int b = 0; b < B; ++b) {
@@ -400,19 +406,11 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     if (R * 3 * (size_t)D * es >= ((size_t)1 << 31))
         return c->fail(-22, "vv_transformer_steps: %zu packed rows make a %zu-byte qkv buffer; kernels address it with 32-bit byte offsets "
                             "(< 2 GiB) -- synthesise fewer units per call", R, R * 3 * (size_t)D * es);
-    std::vector<int> htab(2 * B + Rc + R);              // row_start[2B] | row_src[Rc] | row_pos[R]
-    {
-        int* rs = htab.data(); int* src = rs + 2 * B; int* pos = src + Rc;
-        size_t r = 0;
-        for (int b = 0; b < B; ++b) {
-            rs[b] = (int)r; rs[B + b] = (int)(Rc + r);
-            for (int t = 0; t < hlen[b]; ++t, ++r) { src[r] = b * N + t; pos[r] = t; pos[Rc + r] = t; }
-        }
-    }
+    const size_t n_tab = 2 * (size_t)B + Rc + R;          // row_start[2B] | row_src[Rc] | row_pos[R]
     const int S = c->n_steps;
     Need nd;
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
-    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * htab.size());
+    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * n_tab);
     nd.add(4ull * R * 64); nd.add(4ull * R * 64);
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
@@ -427,12 +425,11 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
     int* kv_len = carve<int>(c, 2 * B);
     float* csq = carve<float>(c, (size_t)N * 64);
     float* csk = carve<float>(c, (size_t)N * 64);
-    int* tab = carve<int>(c, htab.size());
+    int* tab = carve<int>(c, n_tab);
     float* csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
     float* csk_rows = carve<float>(c, R * 64);
-    HIPCHK(c, hipMemcpyAsync(tab, htab.data(), sizeof(int) * htab.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));                 // htab is a local: the copy must be done before it goes away
     const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
+    KCHK(c, vvk_row_tables(seq_len, B, N, (int)Rc, tab, tab + 2 * B, tab + 2 * B + Rc, st, &m__));
     const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? csq_rows : csq, c->rope_rows ? csk_rows : csk};
     KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
     KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
@@ -516,6 +513,21 @@ int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float*
         }
     }
     return 0;
+}
+
+int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float* x, const float* cat, const float* cat_drop,
+                         const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
+                         int step0, int n_steps, void* stream) {
+    return transformer_steps_impl(c, B, N, seq_len, nullptr, x, cat, cat_drop, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, step0, n_steps, stream);
+}
+
+// Same, with the per-item lengths ALSO given on the host (they must equal the device array): no read-back, no stream
+// synchronisation anywhere in the call -- with a workspace that is already large enough it can be captured into a hipGraph.
+int vv_transformer_steps_h(vv_ctx* c, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x, const float* cat,
+                           const float* cat_drop, const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k,
+                           const float* rope_sin_k, int step0, int n_steps, void* stream) {
+    if (c && !seq_len_host) return c->fail(-22, "vv_transformer_steps_h: host lengths missing");
+    return transformer_steps_impl(c, B, N, seq_len, seq_len_host, x, cat, cat_drop, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, step0, n_steps, stream);
 }
 
 // --------------------------------------------------------------------------------------- decode

@@ -259,6 +259,22 @@ __global__ void dup_len_kernel(const int* __restrict__ seq_len, int* __restrict_
     if (b < B) { out[b] = seq_len[b]; out[B + b] = seq_len[b]; }
 }
 
+// Packed-row tables of one vv_transformer_steps call, built on the device from the per-item lengths (one workgroup per item):
+//   row_start[2B] (conditional branch first), row_src[Rc] = b * N + t, row_pos[2 Rc] = t.
+__global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__ seq_len, int B, int N, int Rc, int* __restrict__ row_start,
+                                                         int* __restrict__ row_src, int* __restrict__ row_pos) {
+    const int b = blockIdx.x;
+    int r0 = 0;
+    for (int i = 0; i < b; ++i) r0 += seq_len[i];            // B is at most a few hundred: a serial prefix per workgroup is cheaper than a scan
+    const int len = seq_len[b];
+    if (threadIdx.x == 0) { row_start[b] = r0; row_start[B + b] = Rc + r0; }
+    for (int t = threadIdx.x; t < len; t += 256) {
+        row_src[r0 + t] = b * N + t;
+        row_pos[r0 + t] = t;
+        row_pos[Rc + r0 + t] = t;
+    }
+}
+
 // ---------------------------------------------------------------- K5: GroupNorm, channel-major [B][C][T]
 // One workgroup per (batch item, group): the group's C/G x T slab is contiguous.  Two streaming passes
 // (sum / sum of squared deviations -> numerically the two-pass form), wave-shuffle + LDS reductions, then
@@ -423,6 +439,14 @@ int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int
     VVK_CHECK_LAUNCH();
     return 0;
 }
+int vvk_row_tables(const int* seq_len, int B, int N, int Rc, int* row_start, int* row_src, int* row_pos, hipStream_t st, const char** err) {
+    if (B <= 0 || N <= 0 || Rc <= 0) { *err = "row_tables: empty"; return -22; }
+    row_tables_kernel<<<B, 256, 0, st>>>(seq_len, B, N, Rc, row_start, row_src, row_pos);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err) {
     dup_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(seq_len, out, B);
     VVK_CHECK_LAUNCH();

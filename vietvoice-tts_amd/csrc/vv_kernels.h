@@ -37,6 +37,7 @@ int vvk_ref_len(const int* audio_len, int* ref_len, int B, int hop, hipStream_t 
 int vvk_decode_len(const int* seq_len, const int* ref_len, int* lens, int B, int n_levels, const int* mult, hipStream_t st,
                    const char** err);
 int vvk_dup_len(const int* seq_len, int* out, int B, hipStream_t st, const char** err);
+int vvk_row_tables(const int* seq_len, int B, int N, int Rc, int* row_start, int* row_src, int* row_pos, hipStream_t st, const char** err);
 int vvk_silu(float* x, size_t n, hipStream_t st, const char** err);
 int vvk_resample_poly(const float* x, int n_in, const double* h, int n_taps, int up, int down, int skip, float* y, int n_out,
                       hipStream_t st, const char** err);

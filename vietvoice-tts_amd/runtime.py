@@ -100,6 +100,8 @@ EXPORTS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_transformer_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vv_transformer_steps_h": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vv_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_decode_ws_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
@@ -259,7 +261,7 @@ class HipSynth:
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, audio: torch.Tensor, audio_len: torch.Tensor, text_ids: torch.Tensor, text_len: torch.Tensor,
-                   seq_len: torch.Tensor, N: int, max_audio_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                   seq_len: torch.Tensor, N: int, max_audio_len: Optional[int] = None, seq_len_host=None) -> Dict[str, torch.Tensor]:
         """audio int16 [B,S], text_ids int32 [B,T], *_len int32 [B] -- all on the device."""
         B = audio.shape[0]
         for t, d in ((audio, torch.int16), (audio_len, torch.int32), (text_ids, torch.int32), (text_len, torch.int32), (seq_len, torch.int32)):
@@ -274,6 +276,7 @@ class HipSynth:
                                                text_ids.data_ptr(), text_ids.shape[1], text_len.data_ptr(), seq_len.data_ptr(),
                                                cat.data_ptr(), cat_drop.data_ptr(), ref_len.data_ptr(), self._stream()))
         return {"cat_mel_text": cat, "cat_mel_text_drop": cat_drop, "ref_signal_len": ref_len, "seq_len": seq_len,
+                "seq_len_host": None if seq_len_host is None else [int(v) for v in seq_len_host],
                 "rope_cos_q": self.rope[0][:N], "rope_sin_q": self.rope[1][:N], "rope_cos_k": self.rope[2][:N],
                 "rope_sin_k": self.rope[3][:N]}
 
@@ -283,16 +286,22 @@ class HipSynth:
         es = 2 if self.dt_torch == torch.bfloat16 else 4
         return ((1 << 31) - 1) // (2 * 3 * self.spec.dim * es)
 
-    def transformer_steps(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], step0: int, n_steps: int) -> torch.Tensor:
-        """x fp32 [B,N,n_mel] updated in place on the device."""
+    def transformer_steps(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], step0: int, n_steps: int, seq_len_host=None) -> torch.Tensor:
+        """x fp32 [B,N,n_mel] updated in place on the device.  seq_len_host (optional list / array of the B lengths, the same
+        values as pre["seq_len"]): the call then needs no read-back and no stream synchronisation (vv_transformer_steps_h)."""
         B, N, M = x.shape
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and M == self.spec.n_mel
+        if seq_len_host is None:
+            seq_len_host = pre.get("seq_len_host")
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.vv_transformer_steps(self.ctx, B, N, pre["seq_len"].data_ptr(), x.data_ptr(),
-                                                      pre["cat_mel_text"].data_ptr(), pre["cat_mel_text_drop"].data_ptr(),
-                                                      pre["rope_cos_q"].data_ptr(), pre["rope_sin_q"].data_ptr(),
-                                                      pre["rope_cos_k"].data_ptr(), pre["rope_sin_k"].data_ptr(),
-                                                      step0, n_steps, self._stream()))
+            tail = (pre["cat_mel_text"].data_ptr(), pre["cat_mel_text_drop"].data_ptr(), pre["rope_cos_q"].data_ptr(), pre["rope_sin_q"].data_ptr(),
+                    pre["rope_cos_k"].data_ptr(), pre["rope_sin_k"].data_ptr(), step0, n_steps, self._stream())
+            if seq_len_host is not None:
+                host = (C.c_int32 * B)(*[int(v) for v in seq_len_host])
+                assert len(host) == B
+                self._check(self.lib.vv_transformer_steps_h(self.ctx, B, N, pre["seq_len"].data_ptr(), host, x.data_ptr(), *tail))
+            else:
+                self._check(self.lib.vv_transformer_steps(self.ctx, B, N, pre["seq_len"].data_ptr(), x.data_ptr(), *tail))
         return x
 
     def decode(self, x: torch.Tensor, pre: Dict[str, torch.Tensor], t_gen_max: int, want_wave: bool = False):
@@ -328,10 +337,11 @@ class HipSynth:
         return pcm, pcm_len
 
     def synthesize_batch(self, audio, audio_len, text_ids, text_len, seq_len, N: int, noise: torch.Tensor, t_gen_max: int,
-                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None, gen_frames=None):
+                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None, gen_frames=None, seq_len_host=None):
         """Whole hot path for a batch, state resident in HBM: preprocess -> ODE steps -> vocoder.
-        gen_frames (host list, optional): per-item generated frames; lets the vocoder run in length buckets on ragged batches."""
-        pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len)
+        gen_frames (host list, optional): per-item generated frames; lets the vocoder run in length buckets on ragged batches.
+        seq_len_host (optional): the lengths on the host too -- the Euler-step call then runs without any stream synchronisation."""
+        pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len, seq_len_host=seq_len_host)
         x = noise.clone()
         self.transformer_steps(x, pre, 0, self.n_steps if n_steps is None else n_steps)
         if gen_frames is not None and len(gen_frames) == x.shape[0]:
