@@ -115,7 +115,12 @@ uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context a
 
 /* Context switches (explicit API, never the environment).  "fuse_mrf": run the MRF resblock pairs of the C <= 64 vocoder
  * stages through vv_mrf_resblock's fused kernel -- 0 never (two vv_conv1d launches per pair), 1 always, 2 (default) for
- * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way. */
+ * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way.
+ * "split_k_tail" (bf16 acoustic model): lets vv_transformer_steps take vv_gemm_tail_plan's split-K tail -- 0 never, 1 for the
+ * out-projection and FF2 GEMMs, 2 (default) for FF2 only (the measured optimum at the flagship shape: the parts cost the
+ * consuming norms extra reads).  Rows in the tail sum bf16-rounded K parts in fp32 (same tolerance class as the plain launch,
+ * not bit-identical to it); the fp32 path never splits.
+ * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
 int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
@@ -147,8 +152,15 @@ typedef struct vv_gemm_args {
     const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
     int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
                                   needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */
+    int32_t tail_parts, tail_row0;   /* split-K tail (VV_EPI_GATE_STORE, bf16): both exactly as vv_gemm_tail_plan returns them, 0 = off */
+    void* C_tail;              /* tail_parts > 1: [tail_parts - 1][M - tail_row0][ldc] partial products of rows >= tail_row0; C holds
+                                  part 0 (with the bias), the consumer adds the rest (vv_ln_args.delta_tail) */
 } vv_gemm_args;
 int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
+/* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the
+ * gate-store form can split the K range of the last row panels `parts` ways so that the remainder costs 1/parts of a round.
+ * Returns the plan for this shape on the current device: rows >= row0 are split `parts` ways (parts = 0: nothing to gain). */
+int vv_gemm_tail_plan(vv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts);
 
 typedef struct vv_attn_args {
     int32_t dtype;
@@ -175,6 +187,9 @@ typedef struct vv_ln_args {
     int32_t delta_dtype, ld_delta;
     const void* delta2;     /* optional second delta (same dtype / ld): y = LN((x + delta) + delta2) */
     int32_t keep_x;         /* 1: normalise x + delta but leave x as it is (the caller adds this delta again later, with delta2) */
+    int32_t tail_row0;      /* split-K tails of the deltas (vv_gemm_args.C_tail): rows >= tail_row0 also add */
+    int32_t delta_tail_parts, delta2_tail_parts;   /*   delta_tail [parts - 1][R - tail_row0][ld_delta] (0 / 1 parts = none)  */
+    const void *delta_tail, *delta2_tail;          /*   in part order, right after the delta they belong to                   */
 } vv_ln_args;
 int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
 

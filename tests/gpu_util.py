@@ -21,9 +21,15 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
 
 
+def gemm_tail_plan(eng, M, N, K):
+    row0, parts = C.c_int32(0), C.c_int32(0)
+    check(eng, eng.lib.vv_gemm_tail_plan(eng.ctx, M, N, K, C.byref(row0), C.byref(parts)))
+    return row0.value, parts.value
+
+
 def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0, tile=0,
-         rope_pos=None, rope_by_row=0):
-    """A [M,K], W [N,K] on device, same dtype (bf16 or f32)."""
+         rope_pos=None, rope_by_row=0, tail=None):
+    """A [M,K], W [N,K] on device, same dtype (bf16 or f32).  tail = (C_tail tensor, row0, parts): the split-K tail request."""
     dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
     od = dt if out_dtype is None else out_dtype
     M, K = A.shape
@@ -43,6 +49,8 @@ def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=No
     a.n_store, a.seq_n, a.rope_dim, a.tile = n_store, seq_n, rope_dim, tile
     a.rope_pos = None if rope_pos is None else rope_pos.data_ptr()
     a.rope_by_row = rope_by_row
+    if tail is not None:
+        a.C_tail, a.tail_row0, a.tail_parts = tail[0].data_ptr(), tail[1], tail[2]
     check(eng, eng.lib.vv_gemm(eng.ctx, C.byref(a), stream()))
     torch.cuda.synchronize()
     return C_io

@@ -380,6 +380,79 @@ def test_layernorm_modulate(hip_tiny, D, out_dtype):
         assert gu.rel_err(y, F.layer_norm(xn2, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("N,K,m_tiles,ragged", [(512, 512, 136, 100), (1024, 1024, 68, 0), (1024, 4096, 80, 255), (512, 256, 136, 0)])
+def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
+    """Split-K tail of the persistent gate-store GEMM (vv_gemm_tail_plan): rows below row0 are bit-identical to the plain
+    launch; for rows >= row0 part 0 (+ bias) lands in C and the other K parts in C_tail, and their fp32 sum matches the
+    fp32 product of the same bf16 operands.  Then the consumer: vv_layernorm with delta_tail adds exactly that sum.
+    The last case has too few K-tiles for 4 parts (2 K-tiles each are the minimum) and must take 2."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    M = 256 * m_tiles - ragged
+    row0, parts = gu.gemm_tail_plan(eng, M, N, K)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8
+    tiles = m_tiles * (N // 256)
+    assert tiles % n_cu != 0 and tiles > n_cu, "the case must leave a partial last round on this device"
+    assert parts == (2 if K == 256 else 4) and row0 % 2048 == 0 and 0 < row0 < M
+    assert (row0 // 256) * (N // 256) % n_cu == 0 and (m_tiles - row0 // 256) * (N // 256) * parts <= n_cu
+    g = torch.Generator().manual_seed(N * 7 + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gu.DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(gu.DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(gu.DEV)
+    gate = torch.randn(N, generator=g).to(gu.DEV)
+    plain = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate)
+    want = gate * (A.float() @ W.float().t() + b)
+    for rep in range(2):
+        Ct = torch.full((parts - 1, M - row0, N), 7.0, dtype=torch.bfloat16, device=gu.DEV)
+        got = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, tail=(Ct, row0, parts))
+        assert torch.equal(got[:row0], plain[:row0])
+        total = got[row0:].float() + Ct.float().sum(0)
+        assert gu.rel_err(total, want[row0:]) < TOL_BF16
+        assert gu.rel_err(total, plain[row0:].float()) < TOL_BF16
+        assert not bool((Ct == 7.0).all(dim=-1).any()), "every tail row of every part is written"
+        # the parts really are K ranges: part p alone equals gate * A[:, p-th K range] W^T
+        kq = K // parts
+        for p_ in range(1, parts):
+            wp = gate * (A[row0:, p_ * kq:(p_ + 1) * kq].float() @ W[:, p_ * kq:(p_ + 1) * kq].float().t())
+            assert gu.rel_err(Ct[p_ - 1], wp) < TOL_BF16, p_
+    # a request that is not the plan for the shape is refused, not guessed at
+    a_bad = (Ct, row0 + 2048, parts)
+    with pytest.raises(AssertionError, match="split-K tail"):
+        gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, tail=a_bad)
+    with pytest.raises(AssertionError, match="split-K tail"):
+        gu.gemm(eng, A, W, bias=b, mode=0, tail=(Ct, row0, parts))
+    if N != 1024:
+        return
+    # consumer: LayerNorm adds delta + its tail parts (and a second delta with its own tail) before normalising
+    x = (torch.randn(M, N, generator=g) * 2).to(gu.DEV)
+    sc, sh = (torch.randn(N, generator=g) * 0.3).to(gu.DEV), (torch.randn(N, generator=g) * 0.3).to(gu.DEV)
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=gu.DEV)
+    d2 = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(gu.DEV)
+    d2t = (torch.randn(1, M - row0, N, generator=g) * 0.5).to(torch.bfloat16).to(gu.DEV)
+    for two in (False, True):
+        xx = x.clone()
+        a = rt.vv_ln_args()
+        a.out_dtype = rt.VV_BF16
+        a.x, a.ldx, a.y, a.ldy, a.R, a.D, a.w, a.b, a.add_one, a.eps = xx.data_ptr(), N, y.data_ptr(), N, M, N, sc.data_ptr(), sh.data_ptr(), 1, 1e-6
+        a.delta, a.delta_dtype, a.ld_delta = got.data_ptr(), rt.VV_BF16, N
+        a.tail_row0, a.delta_tail, a.delta_tail_parts = row0, Ct.data_ptr(), parts
+        if two:
+            a.delta2, a.delta2_tail, a.delta2_tail_parts = d2.data_ptr(), d2t.data_ptr(), 2
+        gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        dsum = got.float()
+        dsum[row0:] = (((got[row0:].float() + Ct[0].float()) + Ct[1].float()) + Ct[2].float())      # the kernel's order
+        xn = x + dsum
+        if two:
+            e2 = d2.float()
+            e2[row0:] = e2[row0:] + d2t[0].float()
+            xn = xn + e2
+        assert torch.equal(xx, xn)
+        assert gu.rel_err(y, F.layer_norm(xn, (N,), eps=1e-6) * (sc + 1) + sh) < 1e-2
+    a.delta = None                                                     # a tail without its delta is a caller bug
+    assert eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()) != 0
+
+
 # ------------------------------------------------------------------------------------ conv position embedding
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_posconv(hip_tiny, dtype):

@@ -46,6 +46,10 @@ struct vv_ctx {
     int rope_rows = 0;                  // 1: the QKV rope epilogue reads row-gathered tables (vv_rope_rows).  Off by default: 11 % faster in a
                                         // back-to-back GEMM loop (tables stay cached), 0.9 % SLOWER inside the step, where the 52 MB of row
                                         // tables come from HBM each time while the 0.8 MB position tables stay in L2 (profiles/r02/gemm_notes.md)
+    int split_k_tail = 2;               // bf16 gate-store GEMMs: split the K range of the last row panels when the tile count leaves a partial
+                                        // last round of the persistent kernel (vv_gemm_tail_plan); the LayerNorm adds the parts.  0 off, 1 out-
+                                        // projection and FF2, 2 FF2 only (default: at the flagship shape the out-projection's K = 1024 tail saves
+                                        // 10 us of GEMM and costs as much again in the two norms that read its parts; FF2's K = 4096 tail pays)
     int fuse_mrf = 2;                   // K12 fused MRF pairs (C <= 64 stages): 0 never, 1 always, 2 auto = for decodes of <= 8 items
                                         // (fewer launches win when the stage is launch-bound; at B = 32 the halo recompute costs 1.3 %)
     // profiling
@@ -133,7 +137,7 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
-         int rope_by_row = 0) {
+         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
@@ -141,6 +145,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
+    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -406,12 +411,23 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     if (R * 3 * (size_t)D * es >= ((size_t)1 << 31))
         return c->fail(-22, "vv_transformer_steps: %zu packed rows make a %zu-byte qkv buffer; kernels address it with 32-bit byte offsets "
                             "(< 2 GiB) -- synthesise fewer units per call", R, R * 3 * (size_t)D * es);
+    // split-K tails of the two N = D gate-store GEMMs (out-proj K = D, FF2 K = FF): same row0 (it depends on M and N only)
+    int tail_row0 = 0, tp_o = 0, tp_f = 0;
+    if (c->split_k_tail && c->dt == VV_DTYPE_BF16) {
+        int r0o = 0, r0f = 0;
+        if (c->split_k_tail == 1) vvk_gemm_tail_plan((int)R, D, D, &r0o, &tp_o);
+        vvk_gemm_tail_plan((int)R, D, FF, &r0f, &tp_f);
+        if (tp_o && tp_f && r0o != r0f) tp_o = tp_f = 0;   // cannot happen (row0 is a function of M, N and the CU count); refuse rather than mix
+        tail_row0 = tp_o ? r0o : r0f;
+    }
+    const size_t tail_rows = (tp_o || tp_f) ? R - tail_row0 : 0;
     const size_t n_tab = 2 * (size_t)B + Rc + R;          // row_start[2B] | row_src[Rc] | row_pos[R]
     const int S = c->n_steps;
     Need nd;
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
     nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * n_tab);
     nd.add(4ull * R * 64); nd.add(4ull * R * 64);
+    nd.add(es * tail_rows * D * (tp_o > 1 ? tp_o - 1 : 0)); nd.add(es * tail_rows * D * (tp_f > 1 ? tp_f - 1 : 0));
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
@@ -428,6 +444,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     int* tab = carve<int>(c, n_tab);
     float* csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
     float* csk_rows = carve<float>(c, R * 64);
+    char* h2_tail = carve<char>(c, es * tail_rows * D * (tp_o > 1 ? tp_o - 1 : 0));     // [parts - 1][tail_rows][D] partial deltas
+    char* h3_tail = carve<char>(c, es * tail_rows * D * (tp_f > 1 ? tp_f - 1 : 0));
     const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
     KCHK(c, vvk_row_tables(seq_len, B, N, (int)Rc, tab, tab + 2 * B, tab + 2 * B + Rc, st, &m__));
     const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? csq_rows : csq, c->rope_rows ? csk_rows : csk};
@@ -478,6 +496,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
                               f2w = blk(l, ".ff2.weight"), f2b = blk(l, ".ff2.bias");
             vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
             a.delta_dtype = c->dt; a.ld_delta = D;
+            a.tail_row0 = tail_row0; a.delta_tail = h2_tail; a.delta2_tail = h3_tail;
+            a.delta_tail_parts = pending ? tp_o : 0; a.delta2_tail_parts = pending ? tp_f : 0;
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
@@ -488,12 +508,14 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
                 Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D,
+                             0, nullptr, 0, 0, -1, nullptr, 0, tp_o ? h2_tail : nullptr, tp_o ? tail_row0 : 0, tp_o)) return r;
             a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
-            a.delta = h2; a.delta2 = nullptr; a.keep_x = 1;
+            a.delta = h2; a.delta2 = nullptr; a.keep_x = 1; a.delta_tail_parts = tp_o; a.delta2_tail_parts = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + 2.0 * es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h3, D, (int)R, D, FF, st, mod + 5 * D)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h3, D, (int)R, D, FF, st, mod + 5 * D,
+                             0, nullptr, 0, 0, -1, nullptr, 0, tp_f ? h3_tail : nullptr, tp_f ? tail_row0 : 0, tp_f)) return r;
             pending = true;
         }
         {
@@ -502,6 +524,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
             a.w = fm; a.b = fm + D;                          // scale, shift
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 1;     // x is re-initialised by the next step
             a.delta_dtype = c->dt; a.ld_delta = D;
+            a.tail_row0 = tail_row0; a.delta_tail = h2_tail; a.delta2_tail = h3_tail;
+            a.delta_tail_parts = pending ? tp_o : 0; a.delta2_tail_parts = pending ? tp_f : 0;
             Prof p(c, VV_PROF_NORM, 0, es * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 4.0 * R * D), st);
             KCHK(c, vvk_ln_mod(&a, st, &m__));
         }
@@ -651,6 +675,10 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
     if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
+    if (!strcmp(name, "split_k_tail")) {
+        if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: split_k_tail takes 0 (off), 1 (out-projection and FF2) or 2 (FF2 only)");
+        c->split_k_tail = value; return 0;
+    }
     if (!strcmp(name, "fuse_mrf")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: fuse_mrf takes 0 (off), 1 (on) or 2 (auto)");
         c->fuse_mrf = value; return 0;
@@ -711,6 +739,12 @@ int vv_prof_collect(vv_ctx* c, int64_t* launches, double* ms, double* flops, dou
     } while (0)
 
 int vv_gemm(vv_ctx* c, const vv_gemm_args* a, void* st) { SINGLE(c, vvk_gemm(a, (hipStream_t)st, &m__)); }
+int vv_gemm_tail_plan(vv_ctx* c, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts) {
+    if (!c || !row0 || !parts || M < 1 || N < 1 || K < 1) return c ? c->fail(-22, "vv_gemm_tail_plan: bad arguments") : -22;
+    HIPCHK(c, hipSetDevice(c->device));
+    vvk_gemm_tail_plan(M, N, K, row0, parts);
+    return 0;
+}
 int vv_attention(vv_ctx* c, const vv_attn_args* a, void* st) { SINGLE(c, vvk_attention(a, (hipStream_t)st, &m__)); }
 int vv_layernorm(vv_ctx* c, const vv_ln_args* a, void* st) { SINGLE(c, vvk_ln_mod(a, (hipStream_t)st, &m__)); }
 int vv_posconv(vv_ctx* c, const vv_posconv_args* a, void* st) { SINGLE(c, vvk_posconv(a, (hipStream_t)st, &m__)); }

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
                                                      int R, int D, const float* __restrict__ w,
                                                      const float* __restrict__ b, int add_one, float eps,
                                                      const Td* __restrict__ delta, int ldd, const Td* __restrict__ delta2,
-                                                     int keep_x) {
+                                                     int keep_x, int tail_row0, int tp1, const Td* __restrict__ dt1, int tp2,
+                                                     const Td* __restrict__ dt2) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -24,27 +25,69 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
     float* xr = x + (size_t)row * ldx;
     float4 v[4];
     float s = 0.f;
+    if (delta) {
+        // all loads of the row first (x, delta, delta2: up to 12 independent 16-byte loads in flight), then the adds
+        float4 d[4], d2[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + i * 64;
-        if (c < n4) {
-            v[i] = load4_nt<float>(xr + c * 4);                 // the fp32 stream is far larger than the caches: stream it
-            if (delta) {
-                const float4 d = load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
-                v[i].x += d.x; v[i].y += d.y; v[i].z += d.z; v[i].w += d.w;
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + i * 64;
+            if (c < n4) {
+                v[i] = load4_nt<float>(xr + c * 4);             // the fp32 stream is far larger than the caches: stream it
+                d[i] = load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
+                d2[i] = delta2 ? load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                v[i] = d[i] = d2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (row >= tail_row0) {
+            // rows of a split-K tail (wave-uniform, a few per cent of the rows): the other K parts of each delta join it
+            // first, in part order, so the stream sees one delta per branch as in the rows outside the tail
+            const size_t tr = (size_t)(R - tail_row0), r = (size_t)(row - tail_row0);
+            for (int p = 0; p + 1 < tp1; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < n4) {
+                        const float4 t = load4_nt<Td>(dt1 + (p * tr + r) * ldd + c * 4);
+                        d[i].x += t.x; d[i].y += t.y; d[i].z += t.z; d[i].w += t.w;
+                    }
+                }
+            for (int p = 0; p + 1 < tp2; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < n4) {
+                        const float4 t = load4_nt<Td>(dt2 + (p * tr + r) * ldd + c * 4);
+                        d2[i].x += t.x; d2[i].y += t.y; d2[i].z += t.z; d2[i].w += t.w;
+                    }
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + i * 64;
+            if (c < n4) {
+                v[i].x += d[i].x; v[i].y += d[i].y; v[i].z += d[i].z; v[i].w += d[i].w;
                 if (delta2) {                                // (x + delta) + delta2: the order the one-delta-at-a-time protocol adds in
-                    const float4 d2 = load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4);
-                    v[i].x += d2.x; v[i].y += d2.y; v[i].z += d2.z; v[i].w += d2.w;
+                    v[i].x += d2[i].x; v[i].y += d2[i].y; v[i].z += d2[i].z; v[i].w += d2[i].w;
                 }
                 if (!keep_x) {
                     typedef __attribute__((ext_vector_type(4))) float f4;
                     const f4 w4 = {v[i].x, v[i].y, v[i].z, v[i].w};
                     __builtin_nontemporal_store(w4, (f4*)(xr + c * 4));
                 }
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + i * 64;
+            if (c < n4) {
+                v[i] = load4_nt<float>(xr + c * 4);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            } else {
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
     const float mean = wave_sum(s) / (float)D;
@@ -358,7 +401,13 @@ int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
     const int grid = (a->R + 3) / 4;
     float* x = const_cast<float*>(a->x);
     const bool ob = a->out_dtype == VV_BF16, db = a->delta_dtype == VV_BF16;
-#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta, (const Td*)a->delta2, a->keep_x)
+    const int tp1 = a->delta && a->delta_tail_parts > 1 ? a->delta_tail_parts : 0, tp2 = a->delta2 && a->delta2_tail_parts > 1 ? a->delta2_tail_parts : 0;
+    if ((a->delta_tail_parts > 1 && !a->delta) || (a->delta2_tail_parts > 1 && !a->delta2)) { *err = "ln: a delta tail without its delta"; return -22; }
+    if ((tp1 || tp2) && (a->tail_row0 < 0 || a->tail_row0 >= a->R || (tp1 && !a->delta_tail) || (tp2 && !a->delta2_tail) || tp1 > 8 || tp2 > 8)) {
+        *err = "ln: bad split-K tail (row0 within [0, R), buffers given, at most 8 parts)"; return -22;
+    }
+    const int tail_row0 = (tp1 || tp2) ? a->tail_row0 : a->R;
+#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta, (const Td*)a->delta2, a->keep_x, tail_row0, tp1, (const Td*)a->delta_tail, tp2, (const Td*)a->delta2_tail)
     if (ob && db) LN_GO(bf16, bf16);
     else if (ob) LN_GO(bf16, float);
     else if (db) LN_GO(float, bf16);

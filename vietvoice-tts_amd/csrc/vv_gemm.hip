@@ -54,6 +54,9 @@ struct EpiArgs {
     int n_store;
     int seq_n;
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
+    int ks;                  // split-K tail of the persistent gate-store kernel (tail_plan): K parts of the tail tiles, 1 = no tail
+    int tail_panel0;         // ks > 1: first 256-row panel of the tail (a multiple of 8)
+    char* c_part;            // ks > 1: [ks - 1][M - 256 * tail_panel0][ldc] products of K parts 1.. for the tail rows (part 0 goes to C)
     unsigned seq_rcp;        // ceil(2^32 / seq_n): row -> position without a table when every sequence has seq_n rows (m * seq_n < 2^32)
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
@@ -333,11 +336,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // XCD owns activation panels x, x+8, ... and its blocks walk the (panel, n-tile) list panel-major, so
     // the panel's re-reads by the other n-tiles hit the same L2.  Placement changes speed only.
     const int x = blockIdx.x & 7, jb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int n_entries = (m_tiles > x ? (m_tiles - x + 7) / 8 : 0) * n_tiles;
-    if (jb >= n_entries) return;
-    const int n_my = (n_entries - jb + bpx - 1) / bpx;
-    auto tile_bm = [&](int i) { return (((jb + i * bpx) / n_tiles) * 8 + x) * 256; };
-    auto tile_bn = [&](int i) { return ((jb + i * bpx) % n_tiles) * 256; };
+    // Split-K tail (gate-store mode only, ks > 1): the tile count left a partial last round, so the last row panels
+    // (tail_panel0 .., a multiple of 8: the panel -> XCD label rule is unchanged) are walked AFTER the whole-round part as
+    // (tile, K part) entries; the ks parts of a tile are consecutive entries, part p contracts K-tiles [p, p + 1) * nk / ks.
+    // In the other modes (not linear in the product) ks folds to the constant 1 and the tail walk compiles away.
+    const int ks = MODE == MODE_GATE_STORE ? e.ks : 1;
+    const int mt_main = ks > 1 ? e.tail_panel0 : m_tiles;
+    const int cols = n_tiles * ks;
+    const int n_main = (mt_main > x ? (mt_main - x + 7) / 8 : 0) * n_tiles;
+    const int n_tail = ks > 1 ? (m_tiles - mt_main > x ? (m_tiles - mt_main - x + 7) / 8 : 0) * cols : 0;
+    const int n_my_main = jb < n_main ? (n_main - jb + bpx - 1) / bpx : 0;
+    const int n_my = n_my_main + (jb < n_tail ? (n_tail - jb + bpx - 1) / bpx : 0);
+    if (n_my == 0) return;
+    const int nk_full = K >> 6;                                // >= 2 per entry (host-checked)
+    auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) {
+        if (ks == 1 || i < n_my_main) {
+            const int E = jb + i * bpx;
+            bm_ = ((E / n_tiles) * 8 + x) * 256; bn_ = (E % n_tiles) * 256; part_ = 0; nk_ = nk_full;
+        } else {
+            const int E = jb + (i - n_my_main) * bpx, c = E % cols;
+            bm_ = (mt_main + (E / cols) * 8 + x) * 256; bn_ = (c / ks) * 256; part_ = c % ks; nk_ = nk_full / ks;
+        }
+    };
 
     // ---- LDS-DMA sources (buffer_load ... lds): per-lane 32-bit voffset + SGPR soffset (tile origin, K advance).
     // unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit.
@@ -459,21 +479,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int nk = K >> 6;                                     // >= 2 (host-checked)
+    int nk = nk_full;                                          // K-tiles of the CURRENT entry (the K-tile bodies read it by reference)
     // One K-tile = four phases.  The staging schedule is continuous across tiles: K-tile T of the current tile
     // stages Wn1/Am1 of K-tile T+1 and Wn0/Am0 of K-tile T+2, which roll over into the NEXT tile of this
     // block at the end (its first units land while this tile finishes and runs its epilogue).  Every phase
     // stages, so the counted wait is always vmcnt(8): everything staged more than four phases ago has landed.
     // The last tile of a block "prefetches" itself again (harmless: those slots are free), which keeps the
     // loop free of conditionals; the kernel drains with vmcnt(0) before it exits.
-    auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n) {
+    auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) {
         // relaxed: the 16 epilogue stores of the previous tile are still counted by vmcnt (stores and loads retire in issue
         // order); everything this K-tile reads was staged BEFORE them, so the counted wait may leave them in flight too.
         constexpr bool relaxed = decltype(relaxed_c)::value;
         const char* base = smem + par * (4 * UNIT);
         const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
-        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? T + 1 - nk : T + 1;
-        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? T + 2 - nk : T + 2;
+        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;      // absolute K-tile indices
+        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? kb_n + T + 2 - nk : kb_c + T + 2;
         // ---- phase 0: quadrant (m0, n0)
         read_w(0, base + 0 * UNIT);
         read_a(base + 1 * UNIT);
@@ -508,11 +528,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // the PA set of T+1: vmcnt(2).  The FIRST K-tile of a tile stages nothing in PA (its T+1 set was staged at the start of
     // the previous tile's epilogue, ahead of the 16 output stores, or in the prologue): with G1's counted stores its waits are
     // vmcnt(6 + 16) and vmcnt(2 + 16), so the stores stay in flight for the whole first K-tile.
-    auto ktile2 = [&](auto first_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n) {
+    auto ktile2 = [&](auto first_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) {
         constexpr bool first = decltype(first_c)::value;
         const char* base = smem + par * (4 * UNIT);
         const bool r1 = T + 1 >= nk;
-        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? T + 1 - nk : T + 1;
+        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;
         // ---- PA
         read_w(0, base + 0 * UNIT);
         read_w(1, base + 2 * UNIT);
@@ -530,12 +550,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 
     // prologue = phases -6..-1 of the staging schedule for this block's first tile
     {
-        const int bm0 = tile_bm(0), bn0 = tile_bn(0);
-        stage(T0{}, bm0, bn0, 0, 0); stage(T1{}, bm0, bn0, 0, 0); stage(T2{}, bm0, bn0, 0, 0); stage(T3{}, bm0, bn0, 0, 0);
+        int bm0, bn0, part0, nk0;
+        entry(0, bm0, bn0, part0, nk0);
+        const int kb0 = part0 * nk0;
+        stage(T0{}, bm0, bn0, kb0, 0); stage(T1{}, bm0, bn0, kb0, 0); stage(T2{}, bm0, bn0, kb0, 0); stage(T3{}, bm0, bn0, kb0, 0);
 #ifdef VV_GEMM_P2
-        stage(T0{}, bm0, bn0, 1, 1); stage(T2{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);      // the PA set of K-tile 1
+        stage(T0{}, bm0, bn0, kb0 + 1, 1); stage(T2{}, bm0, bn0, kb0 + 1, 1); stage(T1{}, bm0, bn0, kb0 + 1, 1);      // the PA set of K-tile 1
 #else
-        stage(T0{}, bm0, bn0, 1, 1); stage(T1{}, bm0, bn0, 1, 1);
+        stage(T0{}, bm0, bn0, kb0 + 1, 1); stage(T1{}, bm0, bn0, kb0 + 1, 1);
 #endif
     }
 #ifdef VV_GEMM_G1
@@ -546,8 +568,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
         for (int i = 0; i < 16; ++i)       // past num_records: dropped by the hardware, but issued and counted (distinct offsets: not mergeable)
             __builtin_amdgcn_raw_buffer_store_b128(z4, rs_c, (int)(0x7ffffff0u - 16u * (unsigned)i), 0, 0);
-        if (e.bias) bias_nx = e.bias[tile_bn(0) + wc * 64 + lane];              // compiler-counted: waited for before the loop
-        if constexpr (MODE == MODE_GATE_STORE) gate_nx = e.gate[tile_bn(0) + wc * 64 + lane];
+        int bm0, bn0, part0, nk0;
+        entry(0, bm0, bn0, part0, nk0);
+        if (e.bias) bias_nx = e.bias[bn0 + wc * 64 + lane];              // compiler-counted: waited for before the loop
+        if constexpr (MODE == MODE_GATE_STORE) gate_nx = e.gate[bn0 + wc * 64 + lane];
     }
 #endif
 #ifdef VV_GEMM_P2
@@ -561,12 +585,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     int G = 0;                                                 // global K-tile counter (LDS parity)
     bool stores_pending = false;
     for (int it = 0; it < n_my; ++it) {
-        const int bm = tile_bm(it), bn = tile_bn(it);
+        int bm, bn, part, bm_n, bn_n, part_n, nk_n;
+        entry(it, bm, bn, part, nk);
         const bool last = it + 1 == n_my;
-        const int bm_n = last ? bm : tile_bm(it + 1), bn_n = last ? bn : tile_bn(it + 1);
+        entry(last ? it : it + 1, bm_n, bn_n, part_n, nk_n);
+        const int kb = part * nk, kb_n = part_n * nk_n;
+#ifdef VV_GEMM_G1
+        // K parts 1.. write to the partial buffer [ks - 1][M - row0][ldc] (the consumer adds the parts: vv_layernorm's delta
+        // tails).  The resource base is moved back by row0 rows so that the same global-row offsets address it; only rows
+        // >= row0 are ever stored through it.
+        __amdgpu_buffer_rsrc_t rs_p = rs_c;
+        if constexpr (MODE == MODE_GATE_STORE) {
+            if (part > 0) {
+                const long long row0 = (long long)mt_main * 256;
+                rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(e.c_part + ((long long)(part - 1) * (M - row0) - row0) * ldc * (long long)sizeof(To)), 0,
+                                                         (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
+            }
+        }
+#endif
         // accumulators start at the bias (feature-only), so the epilogue has no bias pass
 #ifdef VV_GEMM_G1
-        const float bias_cur = bias_nx;
+        const float bias_cur = part == 0 ? bias_nx : 0.f;          // the bias belongs to K part 0 only
 #endif
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
@@ -579,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     for (int j = 0; j < 4; ++j) b4[j] = lane_get(bias_cur, nh * 32 + ni * 16 + cq * 4 + j);
                 } else
 #endif
-                if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+                if (e.bias && part == 0) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -589,23 +628,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
 #ifdef VV_GEMM_P2
-        ktile2(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
+        ktile2(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
         ++G;
-        for (int T = 1; T < nk; ++T, ++G) ktile2(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n);
+        for (int T = 1; T < nk; ++T, ++G) ktile2(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
         // the PA set of the NEXT tile's K-tile 1: its slots (the parity of the K-tile just finished) were last read three
         // intervals ago; issued here, ahead of the 16 stores, it is older than them for the first K-tile's counted waits
-        stage(T0{}, bm_n, bn_n, 1, (G & 1) ^ 1); stage(T2{}, bm_n, bn_n, 1, (G & 1) ^ 1); stage(T1{}, bm_n, bn_n, 1, (G & 1) ^ 1);
+        stage(T0{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1); stage(T2{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1); stage(T1{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1);
 #else
         if constexpr (G1) {
-            ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);             // 16 stores (real or dropped) always precede a tile
+            ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);             // 16 stores (real or dropped) always precede a tile
         } else if constexpr (MODE == MODE_STORE) {
-            if (stores_pending) ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
-            else ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
+            if (stores_pending) ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
+            else ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
         } else {
-            ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n);
+            ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
         }
         ++G;
-        for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n);
+        for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
 #endif
         stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && !VV_DBG(e) && bm + 256 <= M && bn + 256 <= e.n_store;
 
@@ -758,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         const int row_first = bm + g * 128 + ps * 32 + q * 8;                  // wave-uniform
                         const bool ok = (lane >> 3) < M - row_first && n0 < e.n_store;
                         const unsigned soff = ((unsigned)row_first * (unsigned)ldc + (unsigned)(bn + wc * 64)) * 2u;
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_p, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
                     } else
 #endif
                     if (m < M && n0 < e.n_store && !(VV_DBG(e) & 128)) {
@@ -841,6 +880,40 @@ struct KernelSetup {
     }
 };
 
+// Split-K tail of the persistent kernel.  One workgroup per CU walks ceil(tiles / n_cu) tiles, so a tile count that is not a
+// multiple of n_cu pays a whole round for the remainder (the flagship's 1600 tiles of the two N = 1024 GEMMs: 6.25 rounds of
+// work in 7).  The plan cuts the row panels into a main part that fills whole rounds and a tail whose tiles are split `parts`
+// ways along K so that tail_tiles * parts entries fill (at most) one more, 1/parts as long, round.  Part 0 lands in C as
+// always; parts 1.. land in a partial buffer [parts - 1][M - row0][ldc] which the consumer adds (vv_ln_args.delta_tail).
+// Returns parts = 0 when there is nothing to gain (no remainder, remainder too large, K too short).
+void tail_plan(int M, int N, int K, int n_cu, int* row0, int* parts) {
+    *row0 = 0; *parts = 0;
+#ifdef VV_GEMM_G1
+    if (N % 256 || K % 64 || M < 4096) return;
+    const int m_tiles = (M + 255) / 256, n_tiles = N / 256, total = m_tiles * n_tiles;
+    const int rounds = total / n_cu;
+    if (rounds < 1 || total % n_cu == 0) return;
+    // whole rounds must be whole panels, in multiples of the 8 XCD labels (each label walks every 8th panel)
+    int main_panels = (int)((long long)rounds * n_cu / n_tiles) / 8 * 8;
+    while (main_panels > 0 && ((long long)main_panels * n_tiles) % n_cu) main_panels -= 8;
+    if (main_panels <= 0) return;
+    const int tail_tiles = (m_tiles - main_panels) * n_tiles, nk = K >> 6;
+    for (int ks = 4; ks >= 2; ks >>= 1)
+        if (tail_tiles * ks <= n_cu && nk % ks == 0 && nk / ks >= 2) { *row0 = main_panels * 256; *parts = ks; return; }
+#endif
+}
+
+int device_cus() {
+    static std::atomic<int> cached{0};
+    int cu = cached.load(std::memory_order_relaxed);
+    if (cu) return cu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+    cu = cu / 8 * 8;
+    cached.store(cu, std::memory_order_relaxed);
+    return cu;
+}
+
 template <int MODE, typename To>
 hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                      hipStream_t st) {
@@ -870,6 +943,11 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
     return hipGetLastError();
 }
 
+inline bool pp_fits(int M, int N, int K, int lda, int ldw, int ldc, size_t out_size, int act) {
+    return K >= 128 && act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31) &&
+           (size_t)M * ldc * out_size < ((size_t)1 << 31);
+}
+
 template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                   hipStream_t st, int force_tile) {
@@ -877,16 +955,19 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
     if constexpr (sizeof(T) == 2) {
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
-        if (big && !(VV_DBG(e) & 12) && K >= 128 && e.act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31) &&
-            (size_t)M * ldc * sizeof(To) < ((size_t)1 << 31))
+        if (big && !(VV_DBG(e) & 12) && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
+    if (e.ks > 1) return hipErrorInvalidValue;                 // a split-K tail exists in the persistent kernel only (vvk_gemm checks)
     if (big && (VV_DBG(e) & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
 
 }  // namespace
+
+// The split-K tail the persistent bf16 gate-store GEMM of this shape would take on the current device (parts = 0: none).
+void vvk_gemm_tail_plan(int M, int N, int K, int* row0, int* parts) { tail_plan(M, N, K, device_cus(), row0, parts); }
 
 // Host launcher.  Returns 0 or a negative errno-style code with a message in err.
 int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
@@ -905,6 +986,16 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.seq_rcp = (unsigned)((((unsigned long long)1 << 32) + (unsigned)e.seq_n - 1) / (unsigned)e.seq_n);
+    e.ks = 1; e.c_part = nullptr; e.tail_panel0 = 0;
+    if (g->tail_parts) {
+        int row0 = 0, parts = 0;
+        if (g->mode == MODE_GATE_STORE && g->dtype == VV_BF16 && g->out_dtype == VV_BF16 && (g->tile == 0 || g->tile == 256))
+            if (pp_fits(g->M, g->N, g->K, g->lda, g->ldw, g->ldc, 2, g->act)) tail_plan(g->M, g->N, g->K, device_cus(), &row0, &parts);
+        if (parts != g->tail_parts || row0 != g->tail_row0 || !g->C_tail || ((uintptr_t)g->C_tail % 16)) {
+            *err = "gemm: split-K tail does not match vv_gemm_tail_plan for this shape"; return -22;
+        }
+        e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
+    }
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
 #ifdef VV_GEMM_ABLATE
     {   // ablation build only (never the shipped library): bits from the environment, read once per process

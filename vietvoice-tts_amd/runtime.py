@@ -50,7 +50,8 @@ class vv_gemm_args(C.Structure):
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("cos_q", C.c_void_p), ("sin_q", C.c_void_p),
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
-                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32)]
+                ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32),
+                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p)]
 
 
 class vv_attn_args(C.Structure):
@@ -63,7 +64,8 @@ class vv_ln_args(C.Structure):
     _fields_ = [("out_dtype", C.c_int32), ("x", C.c_void_p), ("ldx", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("D", C.c_int32), ("w", C.c_void_p), ("b", C.c_void_p), ("add_one", C.c_int32), ("eps", C.c_float),
                 ("delta", C.c_void_p), ("delta_dtype", C.c_int32), ("ld_delta", C.c_int32),
-                ("delta2", C.c_void_p), ("keep_x", C.c_int32)]
+                ("delta2", C.c_void_p), ("keep_x", C.c_int32), ("tail_row0", C.c_int32), ("delta_tail_parts", C.c_int32),
+                ("delta2_tail_parts", C.c_int32), ("delta_tail", C.c_void_p), ("delta2_tail", C.c_void_p)]
 
 
 class vv_posconv_args(C.Structure):
@@ -123,6 +125,7 @@ EXPORTS = {
     "vv_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                C.c_int, C.c_void_p]),
     "vv_rope_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_gemm_tail_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vv_rope_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "vv_resample_poly": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
