@@ -215,8 +215,16 @@ typedef struct vv_conv_args {
     int32_t B, Cin, Cout, T_in, T_out, KW, dil, transposed, up, rows_total, rows_pad, accumulate;
     float pre_slope, out_scale;
     const int32_t* len_in;    /* optional per-item valid input length */
+    const void* W_x3;         /* optional: W split by vv_conv_split_weights; when given, the products run as exact 3-way bf16
+                                 splits on the bf16 matrix pipe (six piece products, fp32 accumulate: fp32 fidelity, ~2.7x less
+                                 matrix time) instead of v_mfma_f32_32x32x2_f32.  Same result class, not bit-identical. */
+    int32_t wg_rows;          /* x3 only: 0 = auto (128-row workgroups of 8 waves when rows_total > 64), 64 = force the 4-wave form */
 } vv_conv_args;
 int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
+/* W fp32 [Cin_pad][KW][rows_pad] -> out [ceil(Cin_pad / 16)][KW][3 pieces][2 octets][rows_pad][8] bf16 (w = h + m + l exactly, each piece the
+ * truncated leading 8 significand bits of the remainder).  vv_conv_split_bytes gives the size of `out` (16-byte aligned). */
+uint64_t vv_conv_split_bytes(int32_t Cin_pad, int32_t KW, int32_t rows_pad);
+int vv_conv_split_weights(vv_ctx* ctx, const float* W, int32_t Cin_pad, int32_t KW, int32_t rows_pad, void* out, void* stream);
 
 /* K12, one (kernel, dilation) pair of an MRF resblock fused through LDS (SURVEY 8(a) K12 / 8(b) vv_mrf_resblock):
  *   out = [accumulate ? out : 0] + out_scale * ( conv2(lrelu(conv1(lrelu(y)))) + y ),  conv1 dilated, conv2 undilated, C -> C.

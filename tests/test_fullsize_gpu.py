@@ -148,13 +148,33 @@ def test_fp32_vocoder_alone_on_the_oracle_state(full_case):
     eng = HipSynth(c["spec"], c["w"], acoustic_dtype="bf16", nfe_step=NFE)
     x = c["xs"][-1].float().unsqueeze(0).to(DEV)          # the float64 oracle's final state, rounded once to fp32
     pre = {"ref_signal_len": torch.tensor([563], dtype=torch.int32, device=DEV), "seq_len": torch.tensor([c["N"]], dtype=torch.int32, device=DEV)}
+    eng.set_option("voc_x3", 0)                             # products on v_mfma_f32_32x32x2_f32 (the fp32 context's default)
     pcm, pcm_len, wave = eng.decode(x, pre, bench.GEN_FRAMES, want_wave=True)
     torch.cuda.synchronize()
     n = c["wave"].numel()
     e_w = float((wave[0, :n].cpu().double() - c["wave"]).abs().max())
+    r_w = float((wave[0, :n].cpu().double() - c["wave"]).pow(2).mean().sqrt())
     diff = (pcm[0, :n].cpu().int() - c["pcm"].int()).abs()
-    print(f"\n[full vocoder] waveform max abs err {e_w:.2e}; PCM max diff {int(diff.max())} LSB on {int((diff > 0).sum())} of {n} samples")
+    print(f"\n[full vocoder] waveform max abs err {e_w:.2e} (rms {r_w:.2e}); PCM max diff {int(diff.max())} LSB on {int((diff > 0).sum())} of {n} samples")
     assert int(pcm_len[0]) == n and e_w < 1e-5 and int(diff.max()) <= 1
+    # x3: the same graph with every conv product taken as an exact 3-way bf16 split on the bf16 matrix pipe (the bf16 context's
+    # default).  Same tolerance against the float64 oracle as the f32 instruction; the two fp32-class results differ from each
+    # other by accumulation rounding only.
+    eng.set_option("voc_x3", 1)
+    pcm3, len3, wave3 = eng.decode(x, pre, bench.GEN_FRAMES, want_wave=True)
+    torch.cuda.synchronize()
+    e3 = float((wave3[0, :n].cpu().double() - c["wave"]).abs().max())
+    r3 = float((wave3[0, :n].cpu().double() - c["wave"]).pow(2).mean().sqrt())
+    diff3 = (pcm3[0, :n].cpu().int() - c["pcm"].int()).abs()
+    print(f"[full vocoder x3] waveform max abs err {e3:.2e} (rms {r3:.2e}); PCM max diff {int(diff3.max())} LSB on {int((diff3 > 0).sum())} of {n} samples; "
+          f"x3 vs f32-MFMA waveform max diff {float((wave3 - wave).abs().max()):.2e}")
+    assert int(len3[0]) == n and e3 < 1e-5 and int(diff3.max()) <= 1 and r3 <= 2.0 * r_w + 1e-7
+    eng.prof_enable(True)
+    eng.decode(x, pre, bench.GEN_FRAMES)
+    pr = eng.prof_collect()["voc_conv"]
+    print(f"[full vocoder x3] {pr['launches']} conv launches, {pr['ms']:.3f} ms (B = 1)")
+    eng.prof_enable(False)
+    eng.set_option("voc_x3", 0)
     # K12: the fused MRF pairs (stages with C = 64 and 32, 18 of the 36 pairs) against two launches per pair: bit-identical
     eng.set_option("fuse_mrf", 0)
     pcm_u, len_u, wave_u = eng.decode(x, pre, bench.GEN_FRAMES, want_wave=True)

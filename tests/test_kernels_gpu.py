@@ -494,7 +494,19 @@ def _pack_conv(w):        # torch [Cout][Cin][KW] -> [Cin_pad8][KW][Cout_pad64]
     return t
 
 
-def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pre_slope=1.0, scale=1.0, accumulate=0, out0=None, lens=None):
+def _split_conv_weights(eng, rt, gu, dw):
+    """vv_conv_split_weights on a packed fp32 slab [Cin_pad][KW][rows_pad] (device) -> the x3 slab (device uint16 tensor)."""
+    cin_pad, kw, rows_pad = dw.shape
+    nbytes = int(eng.lib.vv_conv_split_bytes(cin_pad, kw, rows_pad))
+    assert nbytes == (cin_pad + 15) // 16 * kw * 3 * rows_pad * 16 * 2
+    wb = torch.zeros(nbytes // 2, dtype=torch.int16, device=gu.DEV)
+    gu.check(eng, eng.lib.vv_conv_split_weights(eng.ctx, dw.data_ptr(), cin_pad, kw, rows_pad, wb.data_ptr(), gu.stream()))
+    torch.cuda.synchronize()
+    return wb
+
+
+def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pre_slope=1.0, scale=1.0, accumulate=0, out0=None, lens=None,
+              x3=False):
     B, cin, T_in = x.shape
     out = out0.clone().to(gu.DEV) if out0 is not None else torch.zeros(B, cout, T_out, device=gu.DEV)
     dx, dw, db = x.to(gu.DEV), wp.to(gu.DEV), bias.to(gu.DEV)
@@ -509,14 +521,19 @@ def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pr
     a.rows_pad = (a.rows_total + 63) // 64 * 64
     a.accumulate, a.pre_slope, a.out_scale = accumulate, pre_slope, scale
     a.len_in = dl.data_ptr() if dl is not None else None
+    if x3:
+        wb = _split_conv_weights(eng, rt, gu, dw)
+        a.W_x3 = wb.data_ptr()
+        a.wg_rows = x3 if (isinstance(x3, int) and not isinstance(x3, bool)) else 0      # 64: the 4-wave workgroup form
     gu.check(eng, eng.lib.vv_conv1d(eng.ctx, C.byref(a), gu.stream()))
     torch.cuda.synchronize()
     return out
 
 
+@pytest.mark.parametrize("x3", [False, True, 64])         # f32 MFMA / x3 (8-wave workgroups for > 64 rows) / x3 forced to 4-wave workgroups
 @pytest.mark.parametrize("KW,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5), (7, 1)])
 @pytest.mark.parametrize("cin,cout,T", [(20, 24, 300), (64, 64, 517), (100, 128, 40)])
-def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T):
+def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T, x3):
     rt, gu = _imports()
     eng = hip_tiny["f32"]
     g = torch.Generator().manual_seed(KW * 100 + dil + cin)
@@ -527,11 +544,42 @@ def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T):
     res = torch.randn(B, cout, T, generator=g)
     prev = torch.randn(B, cout, T, generator=g)
     ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=dil, padding=dil * (KW - 1) // 2)
-    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, pre_slope=0.1)
+    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, pre_slope=0.1, x3=x3)
     assert gu.rel_err(got, ref) < TOL_F32
     ref2 = prev + (ref + res) / 3.0
-    got2 = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, resid=res, pre_slope=0.1, scale=1.0 / 3.0, accumulate=1, out0=prev)
+    got2 = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, resid=res, pre_slope=0.1, scale=1.0 / 3.0, accumulate=1, out0=prev, x3=x3)
     assert gu.rel_err(got2, ref2) < TOL_F32
+
+
+def test_conv_x3_split_is_exact_and_products_keep_fp32_fidelity(hip_tiny):
+    """The x3 form (vv_vocoder_x3.hip): (a) vv_conv_split_weights is an error-free transformation -- the three bf16 pieces of
+    every weight sum back to the fp32 weight EXACTLY, each piece has at most 8 significant bits by construction, zero padding
+    stays zero; (b) a conv through the six piece products is as close to the float64 result as the v_mfma_f32_32x32x2_f32 path
+    (the two differ from float64 by fp32 accumulation rounding; the dropped piece products are <= 2^-23 of a term)."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(4242)
+    cin, cout, KW, T, dil = 100, 128, 7, 700, 3
+    w = torch.randn(cout, cin, KW, generator=g) / math.sqrt(cin * KW)
+    ws_ = w.clone()
+    ws_[0, 0, 0], ws_[1, 0, 0], ws_[2, 0, 0] = 1.0 + 2.0 ** -23, -3.0e-7, 16777215.0        # low bit set / tiny / all 24 bits set
+    wp = _pack_conv(ws_).to(gu.DEV)
+    wb = _split_conv_weights(eng, rt, gu, wp)
+    cin_pad, _, rows_pad = wp.shape
+    pieces = (wb.view(torch.int16).to(torch.int32) << 16).view(torch.float32).reshape((cin_pad + 15) // 16, KW, 3, 2, rows_pad, 8)
+    back = pieces.double().sum(2).permute(0, 2, 4, 1, 3).reshape(-1, KW, rows_pad)                   # [chunk][octet][8] = c (padded to 16), [kw][row]
+    assert torch.equal(back[:cin_pad], wp.double()), "h + m + l must reproduce every fp32 weight exactly"
+    assert not bool(back[cin_pad:].any()), "channels past Cin_pad are zero"
+    mant = pieces.abs().view(torch.int32) & 0xFFFF
+    assert not bool(mant.any()), "every piece is a bf16 value (low 16 bits of its fp32 pattern are zero)"
+    x = torch.randn(2, cin, T, generator=g) * 3
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), dilation=dil, padding=dil * (KW - 1) // 2)
+    d32 = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, pre_slope=0.1).cpu().double() - ref
+    dx3 = _run_conv(eng, rt, gu, x, _pack_conv(w), b, cout, T, KW, dil, 0, pre_slope=0.1, x3=True).cpu().double() - ref
+    e32, ex3, r32, rx3 = float(d32.abs().max()), float(dx3.abs().max()), float(d32.pow(2).mean().sqrt()), float(dx3.pow(2).mean().sqrt())
+    print(f"\n[conv x3] vs float64 (|ref| max {float(ref.abs().max()):.2f}): f32 MFMA max {e32:.3e} rms {r32:.3e}; 3-way bf16 split max {ex3:.3e} rms {rx3:.3e}")
+    assert ex3 <= 2.0 * e32 and rx3 <= 2.0 * r32
 
 
 @pytest.mark.parametrize("KW,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5)])
@@ -575,7 +623,8 @@ def test_mrf_resblock_fused_is_bit_identical_to_two_convs(hip_tiny, KW, dil, C_,
     assert eng.lib.vv_mrf_resblock(eng.ctx, C.byref(a), gu.stream()) != 0            # wider stages are refused (intermediate does not fit)
 
 
-def test_conv1d_length_mask(hip_tiny):
+@pytest.mark.parametrize("x3", [False, True])
+def test_conv1d_length_mask(hip_tiny, x3):
     rt, gu = _imports()
     eng = hip_tiny["f32"]
     g = torch.Generator().manual_seed(9)
@@ -583,14 +632,15 @@ def test_conv1d_length_mask(hip_tiny):
     w = torch.randn(16, 16, 7, generator=g) / 10
     b = torch.zeros(16)
     lens = [300, 123]
-    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, 16, 300, 7, 3, 0, lens=lens)
+    got = _run_conv(eng, rt, gu, x, _pack_conv(w), b, 16, 300, 7, 3, 0, lens=lens, x3=x3)
     for i, L in enumerate(lens):
         ref = F.conv1d(x[i:i + 1, :, :L], w, b, dilation=3, padding=9)
         assert gu.rel_err(got[i:i + 1, :, :L], ref) < TOL_F32
 
 
+@pytest.mark.parametrize("x3", [False, True, 64])
 @pytest.mark.parametrize("u,cin,cout,T", [(8, 32, 16, 70), (2, 16, 8, 300), (8, 64, 32, 257), (2, 128, 64, 40)])
-def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T):
+def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T, x3):
     rt, gu = _imports()
     eng = hip_tiny["f32"]
     g = torch.Generator().manual_seed(u * 31 + cin)
@@ -602,7 +652,7 @@ def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T):
     rows = cout * u
     wp = torch.zeros(((cin + 7) // 8 * 8, 2, (rows + 63) // 64 * 64))
     wp[:cin, :, :rows] = w.reshape(cin, cout, 2, u).permute(0, 2, 1, 3).reshape(cin, 2, rows)
-    got = _run_conv(eng, rt, gu, x, wp, b, cout, T * u, 2, 1, u, pre_slope=0.1)
+    got = _run_conv(eng, rt, gu, x, wp, b, cout, T * u, 2, 1, u, pre_slope=0.1, x3=x3)
     assert ref.shape == got.shape
     assert gu.rel_err(got, ref) < TOL_F32
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvvtts_hip.so")
-SOURCES = ["vv_gemm", "vv_attention", "vv_elementwise", "vv_posconv", "vv_vocoder", "vv_mel", "vv_ingest", "vv_api"]
+SOURCES = ["vv_gemm", "vv_attention", "vv_elementwise", "vv_posconv", "vv_vocoder", "vv_vocoder_x3", "vv_mel", "vv_ingest", "vv_api"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 EXTRA_FLAGS = {}      # per-file extras (none needed at present)
 

@@ -50,6 +50,11 @@ struct vv_ctx {
                                         // last round of the persistent kernel (vv_gemm_tail_plan); the LayerNorm adds the parts.  0 off, 1 out-
                                         // projection and FF2, 2 FF2 only (default: at the flagship shape the out-projection's K = 1024 tail saves
                                         // 10 us of GEMM and costs as much again in the two norms that read its parts; FF2's K = 4096 tail pays)
+    int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
+                                        // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
+                                        // context: 1, fp32 context: 0 -- the numerics configuration stays on the f32 instruction)
+    char* x3_buf = nullptr;             // split weight slabs of every vocoder conv (built by vv_finalize_weights)
+    std::map<std::string, const void*> x3_w;
     int fuse_mrf = 2;                   // K12 fused MRF pairs (C <= 64 stages): 0 never, 1 always, 2 auto = for decodes of <= 8 items
                                         // (fewer launches win when the stage is launch-bound; at B = 32 the halo recompute costs 1.3 %)
     // profiling
@@ -199,6 +204,7 @@ void vv_destroy(vv_ctx* c) {
     if (c->modtab) hipFree(c->modtab);
     if (c->fintab) hipFree(c->fintab);
     if (c->d_mult) hipFree(c->d_mult);
+    if (c->x3_buf) hipFree(c->x3_buf);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->pool) hipEventDestroy(e);
     delete c;
@@ -252,16 +258,21 @@ int vv_finalize_weights(vv_ctx* c) {
     need("final.adaln.weight", 4ull * 2 * D * D); need("final.adaln.bias", 4ull * 2 * D);
     need("final.proj.weight", (uint64_t)es * MP * D); need("final.proj.bias", 4ull * MP);
     int ch = g.voc_pre_ch;
+    struct ConvW { std::string name; int cin_pad, kw, rows_pad; };
+    std::vector<ConvW> convs;                              // every vocoder conv slab [cin_pad][kw][rows_pad]: split for the x3 kernels below
+    convs.push_back({"voc.pre.weight", pad_to(g.n_mel, 8), g.voc_pre_k, pad_to(ch, 64)});
     need("voc.pre.weight", 4ull * pad_to(g.n_mel, 8) * g.voc_pre_k * pad_to(ch, 64)); need("voc.pre.bias", 4ull * ch);
     for (int s = 0; s < g.voc_n_up; ++s) {
         const int cin = ch, cout = ch / 2, u = g.voc_up_rates[s];
         const std::string p = "voc.up." + std::to_string(s);
         need(p + ".weight", 4ull * pad_to(cin, 8) * 2 * pad_to(cout * u, 64)); need(p + ".bias", 4ull * cout);
+        convs.push_back({p + ".weight", pad_to(cin, 8), 2, pad_to(cout * u, 64)});
         for (int a = 0; a < g.voc_n_res; ++a)
             for (int b = 0; b < g.voc_n_dil; ++b)
                 for (int k = 1; k <= 2; ++k) {
                     const std::string q = "voc.res." + std::to_string(s) + "." + std::to_string(a) + "." + std::to_string(b) + ".conv" + std::to_string(k);
                     need(q + ".weight", 4ull * pad_to(cout, 8) * g.voc_res_kernels[a] * pad_to(cout, 64)); need(q + ".bias", 4ull * cout);
+                    convs.push_back({q + ".weight", pad_to(cout, 8), g.voc_res_kernels[a], pad_to(cout, 64)});
                 }
         ch = cout;
     }
@@ -269,6 +280,23 @@ int vv_finalize_weights(vv_ctx* c) {
     if (!missing.empty()) return c->fail(-2, "missing or short weights: %s", missing.c_str());
     hipSetDevice(c->device);
     HIPCHK(c, hipMemcpy(&c->post_bias, c->W("voc.post.bias"), 4, hipMemcpyDeviceToHost));
+    {   // x3 slabs: w = h + m + l in bf16 pieces, [chunk][kw][piece][row][16] (vv_vocoder_x3.hip); 1.5x the fp32 bytes
+        size_t total = 0;
+        for (const ConvW& w : convs) total = align_up(total, 256) + vvk_conv_split_bytes(w.cin_pad, w.kw, w.rows_pad);
+        if (c->x3_buf) { HIPCHK(c, hipFree(c->x3_buf)); c->x3_buf = nullptr; }
+        c->x3_w.clear();
+        HIPCHK(c, hipMalloc((void**)&c->x3_buf, total));
+        size_t off = 0;
+        for (const ConvW& w : convs) {
+            off = align_up(off, 256);
+            const char* m__ = "";
+            if (int r = vvk_conv_split_weights(c->Wf(w.name), w.cin_pad, w.kw, w.rows_pad, c->x3_buf + off, nullptr, &m__))
+                return c->fail(r, "%s (%s)", m__, w.name.c_str());
+            c->x3_w[w.name] = c->x3_buf + off;
+            off += vvk_conv_split_bytes(w.cin_pad, w.kw, w.rows_pad);
+        }
+        HIPCHK(c, hipStreamSynchronize(nullptr));
+    }
     // decode length multipliers: level 0 = frames, level s+1 = after upsample s
     std::vector<int> mult(g.voc_n_up + 1, 1);
     for (int s = 0; s < g.voc_n_up; ++s) mult[s + 1] = mult[s] * g.voc_up_rates[s];
@@ -606,10 +634,16 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
         Prof p(c, VV_PROF_ELEMWISE, 0, 8.0 * B * M * Ts[0], st);
         KCHK(c, vvk_mel_slice(x, B, N, M, ref_len, seq_len, v0, Ts[0], st, &m__));
     }
+    const bool x3 = c->voc_x3 == 1 || (c->voc_x3 < 0 && c->dt == VV_DTYPE_BF16);
     auto conv = [&](const float* in, const std::string& name, float* out, const float* resid, int Cin, int Cout, int T_in, int T_out, int KW,
                     int dil, int up, float pre_slope, float scale, int accumulate, const int* len_in) -> int {
         vv_conv_args a{};
         a.in = in; a.W = c->Wf(name + ".weight"); a.bias = c->Wf(name + ".bias"); a.out = out; a.resid = resid;
+        if (x3) {
+            auto it = c->x3_w.find(name + ".weight");
+            if (it == c->x3_w.end()) return c->fail(-2, "split weights of %s missing", name.c_str());
+            a.W_x3 = it->second;
+        }
         a.B = B; a.Cin = Cin; a.Cout = Cout; a.T_in = T_in; a.T_out = T_out; a.KW = KW; a.dil = dil; a.transposed = up > 0; a.up = up;
         a.rows_total = up > 0 ? Cout * up : Cout; a.rows_pad = pad_to(a.rows_total, 64); a.accumulate = accumulate;
         a.pre_slope = pre_slope; a.out_scale = scale; a.len_in = len_in;
@@ -641,7 +675,8 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
                 const bool last = b == g.voc_n_dil - 1;
                 float* dst = last ? acc : ((y == ya) ? yb : ya);
                 const int kw = g.voc_res_kernels[a], dil = g.voc_res_dilations[b];
-                if ((c->fuse_mrf == 1 || (c->fuse_mrf == 2 && B <= 8)) && (C == 32 || C == 64) && (kw == 3 || kw == 7 || kw == 11)) {
+                // (the fused pair exists on the f32 instruction only: with x3 products the two x3 launches are taken unless fusion is forced)
+                if ((c->fuse_mrf == 1 || (c->fuse_mrf == 2 && B <= 8 && !x3)) && (C == 32 || C == 64) && (kw == 3 || kw == 7 || kw == 11)) {
                     // K12 fused through LDS: the intermediate of the pair never reaches HBM (bit-identical to the two launches below)
                     vv_mrf_args m{};
                     m.y = y; m.W1 = c->Wf(q + ".conv1.weight"); m.b1 = c->Wf(q + ".conv1.bias"); m.W2 = c->Wf(q + ".conv2.weight"); m.b2 = c->Wf(q + ".conv2.bias");
@@ -675,6 +710,10 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
     if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
+    if (!strcmp(name, "voc_x3")) {
+        if (value < -1 || value > 1) return c->fail(-22, "vv_set_option: voc_x3 takes -1 (by acoustic dtype), 0 (f32 MFMA) or 1 (3-way bf16 split)");
+        c->voc_x3 = value; return 0;
+    }
     if (!strcmp(name, "split_k_tail")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: split_k_tail takes 0 (off), 1 (out-projection and FF2) or 2 (FF2 only)");
         c->split_k_tail = value; return 0;
@@ -749,6 +788,12 @@ int vv_attention(vv_ctx* c, const vv_attn_args* a, void* st) { SINGLE(c, vvk_att
 int vv_layernorm(vv_ctx* c, const vv_ln_args* a, void* st) { SINGLE(c, vvk_ln_mod(a, (hipStream_t)st, &m__)); }
 int vv_posconv(vv_ctx* c, const vv_posconv_args* a, void* st) { SINGLE(c, vvk_posconv(a, (hipStream_t)st, &m__)); }
 int vv_conv1d(vv_ctx* c, const vv_conv_args* a, void* st) { SINGLE(c, vvk_conv(a, (hipStream_t)st, &m__)); }
+uint64_t vv_conv_split_bytes(int32_t Cin_pad, int32_t KW, int32_t rows_pad) {
+    return (Cin_pad < 1 || KW < 1 || rows_pad < 1) ? 0 : (uint64_t)vvk_conv_split_bytes(Cin_pad, KW, rows_pad);
+}
+int vv_conv_split_weights(vv_ctx* c, const float* W, int32_t Cin_pad, int32_t KW, int32_t rows_pad, void* out, void* st) {
+    SINGLE(c, vvk_conv_split_weights(W, Cin_pad, KW, rows_pad, out, (hipStream_t)st, &m__));
+}
 int vv_mrf_resblock(vv_ctx* c, const vv_mrf_args* a, void* st) { SINGLE(c, vvk_mrf_pair(a, (hipStream_t)st, &m__)); }
 int vv_conv_post(vv_ctx* c, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T,
                  int KW, float pre_slope, const int32_t* len_in, void* st) {

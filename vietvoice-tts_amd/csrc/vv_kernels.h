@@ -14,6 +14,9 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err);
 int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err);
 int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err);
 int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err);
+int vvk_conv_x3(const vv_conv_args* a, hipStream_t st, const char** err);
+size_t vvk_conv_split_bytes(int Cin_pad, int KW, int rows_pad);
+int vvk_conv_split_weights(const float* Wt, int Cin_pad, int KW, int rows_pad, void* Wb, hipStream_t st, const char** err);
 int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err);
 int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32, int B, int C, int T,
                   int KW, float pre_slope, const int* len_in, hipStream_t st, const char** err);

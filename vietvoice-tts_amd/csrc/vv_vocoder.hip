@@ -470,9 +470,11 @@ int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
         if (a->KW != 2 || a->up < 2 || (a->up & 1) || a->rows_total != a->Cout * a->up || a->T_out != a->T_in * a->up) {
             *err = "conv: transposed form needs kernel = 2*stride, even stride"; return -22;
         }
+        if (a->W_x3) return vvk_conv_x3(a, st, err);            // split-bf16 products (vv_vocoder_x3.hip), same contract
         launch_conv<2, true, 16>(a, st);
     } else {
         if (a->rows_total != a->Cout || a->T_out != a->T_in || a->dil < 1 || a->dil > 5) { *err = "conv: bad conv shape (dilation 1..5)"; return -22; }
+        if (a->W_x3) return vvk_conv_x3(a, st, err);
         switch (a->KW) {
             case 3: launch_conv<3, false, 8>(a, st); break;
             case 7: launch_conv<7, false, 4>(a, st); break;

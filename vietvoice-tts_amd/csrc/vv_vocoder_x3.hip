@@ -1,0 +1,338 @@
+// K11x: the vocoder's conv1d / ConvTranspose1d implicit GEMM (vv_vocoder.hip, K11) on the bf16 matrix pipe with fp32
+// fidelity -- "x3": every fp32 operand is cut into THREE bf16 pieces, a = h + m + l EXACTLY (24 significand bits = 3 x 8,
+// each piece the truncated leading 8 bits of what is left; bf16 has fp32's exponent range, so nothing over- or underflows),
+// and the product a * w is taken as the six piece products whose weight is >= 2^-16 of it,
+//        h.l + l.h + m.m + h.m + m.h + h.h        (dropped: m.l + l.m + l.l <= 2^-23 |a w|),
+// each an exact 16-bit product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The error of a contraction is that of an
+// fp32 FMA chain (one fp32 rounding per accumulation step, 2^-24) plus 2^-23 per term: the same class as the exact-f32 MFMA
+// of K11, at 6 x 32 cycles per 32x32x16 block instead of 8 x 64 (v_mfma_f32_32x32x2_f32): 2.7x less matrix-pipe time in a
+// kernel class that is matrix-pipe bound in fp32 (profiles/r02/vocoder_notes.md).  Parity against the float64 oracle is
+// asserted at the fp32 path's own tolerance (tests/test_kernels_gpu.py, tests/test_fullsize_gpu.py).
+//
+// Layout.  Weights are split ONCE (vvk_conv_split_weights, at vv_finalize_weights) into
+//        Wb[chunk = ci / 16][kw][piece 3][octet = (ci % 16) / 8][row (rows_pad)][ci % 8]   bf16,
+// rows = co (conv) or co * up + phase (transposed, polyphase as in K11).  A workgroup owns VR = 32 RT rows x 256 time steps;
+// the K loop walks 16 input channels at a time: the input window [q0 - left, q0 + 256 + span - left) of the 16 channels is
+// loaded (LeakyReLU fused, zero outside [0, len)), split, and stored as xs[piece][octet][time][8 ch] -- an MFMA B fragment
+// (column = time, 8 consecutive channels = one octet) is then ONE 16-byte LDS read, and the 32 lanes of a k-half read 32
+// CONSECUTIVE 16-byte slots: ds_read_b128 serves fixed 16-lane groups, each of which then covers all 64 banks (an interleaved
+// [time][16 ch] image, lanes 32 bytes apart, is 2-way conflicted: measured 4 % slower over the decode shapes) -- and the weight slab of a
+// group of TG taps as ws[tap][piece][octet][row][8 ch] (A fragments likewise).  Epilogue as K11.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+
+#include "vv_common.h"
+#include "vv_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;      // a native vector (HIP's uint4 is a struct of unions: register arrays of it end up in scratch)
+
+constexpr int XT = 256;       // time steps per workgroup
+
+__device__ __forceinline__ float lrelu_x(float x, float slope) { return x >= 0.f ? x : x * slope; }
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Pair form of lrelu + split3 for the staging loop (v_pk_mul_f32 / v_pk_add_f32: one instruction per two elements; the max as
+// the bare instruction -- fmaxf would add a canonicalising multiply).  slope in (0, 1]: lrelu(x) = max(x, slope x).
+__device__ __forceinline__ void lrelu_split3_pair(float a0, float a1, float slope, unsigned& h01, unsigned& m01, unsigned& l01) {
+    const f32x2 a = {a0, a1};
+    const f32x2 sa = a * slope;
+    f32x2 v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(a.x), "v"(sa.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(a.y), "v"(sa.y));
+    const unsigned h0 = __float_as_uint(v.x) & 0xffff0000u, h1 = __float_as_uint(v.y) & 0xffff0000u;
+    const f32x2 hv = {__uint_as_float(h0), __uint_as_float(h1)};
+    const f32x2 r1 = v - hv;
+    const unsigned m0 = __float_as_uint(r1.x) & 0xffff0000u, m1 = __float_as_uint(r1.y) & 0xffff0000u;
+    const f32x2 mv = {__uint_as_float(m0), __uint_as_float(m1)};
+    const f32x2 r2 = r1 - mv;
+    h01 = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    m01 = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    l01 = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
+}
+
+// a = h + m + l exactly; the pieces are fp32 bit patterns whose low 16 bits are zero (bf16 in the high half)
+__device__ __forceinline__ void split3(float a, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(a) & 0xffff0000u;
+    const float r1 = a - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2);
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {      // (bf16 of lo_elem) | (bf16 of hi_elem) << 16
+    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
+}
+
+// ---- weight split: Wt fp32 [Cin_pad][KW][rows_pad]  ->  Wb [chunks][KW][3][rows_pad][16]
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ Wt, uint16_t* __restrict__ Wb, int Cin_pad, int KW,
+                                                            int rows_pad, int chunks) {
+    const size_t n = (size_t)chunks * KW * rows_pad * 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i & 15);
+        const size_t t = i >> 4;
+        const int row = (int)(t % rows_pad);
+        const int kw = (int)((t / rows_pad) % KW);
+        const int chunk = (int)(t / ((size_t)rows_pad * KW));
+        const int c = chunk * 16 + j;
+        const float w = c < Cin_pad ? Wt[((size_t)c * KW + kw) * rows_pad + row] : 0.f;
+        unsigned h, m, l;
+        split3(w, h, m, l);
+        const size_t base = (((size_t)chunk * KW + kw) * 3) * 2 * rows_pad;           // [piece][octet][row][8]
+        const size_t in_piece = ((size_t)(j >> 3) * rows_pad + row) * 8 + (j & 7);
+        Wb[(base + 0 * 2 * (size_t)rows_pad) * 8 + in_piece] = (uint16_t)(h >> 16);
+        Wb[(base + 1 * 2 * (size_t)rows_pad) * 8 + in_piece] = (uint16_t)(m >> 16);
+        Wb[(base + 2 * 2 * (size_t)rows_pad) * 8 + in_piece] = (uint16_t)(l >> 16);
+    }
+}
+
+// KW: taps.  TR: polyphase ConvTranspose (KW must be 2).  RT: 32-row MFMA tiles per wave (a workgroup = 4 waves owns
+// 32 RT rows x 256 time steps, wave w the columns [64 w, 64 w + 64)).  TG: taps per weight phase.
+//
+// Pipeline.  The K loop is a sequence of phases (16-channel chunk, group of <= TG taps).  The weight slab of a phase is
+// double-buffered in LDS: phase p loads the slab of phase p + 1 into registers BEFORE its MFMA block and stores it to the other
+// buffer AFTER it (that buffer was last read in phase p - 1, which every wave left before the barrier that opened phase p), so
+// the load has the whole MFMA block to land and a phase costs one barrier.  The input window of chunk c + 1 is loaded into
+// registers before the MFMA block of chunk c's last phase and split / stored behind the next barrier (+ one barrier to publish).
+// NWV: waves per workgroup, 4 (one row group) or 8 (two row groups of 32 RT rows sharing the staged window: the window is
+// loaded and split once for 64 RT rows -- the stages with >= 128 rows).
+template <int KW, bool TR, int RT, int TG, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, RT == 1 ? 3 : 2))) void conv_x3_kernel(const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias,
+                                                         float* __restrict__ out, const float* __restrict__ resid, int Cin, int rows_total,
+                                                         int rows_pad, int T_in, int T_out, int Cout, int dil, int up, float pre_slope,
+                                                         float out_scale, int accumulate, const int* __restrict__ len_in) {
+    constexpr int NT = 64 * NWV;                       // threads
+    constexpr int VR = (NWV / 4) * RT * 32;            // rows per workgroup
+    constexpr int NIT = (2 * (XT + 50) + NT - 1) / NT; // window items (time, channel octet) per thread: 2 (256 + span), span <= 50
+    constexpr int NPH = (KW + TG - 1) / TG;            // phases per chunk
+    constexpr int NW = (TG * 3 * VR * 2 + NT - 1) / NT;  // 16-byte weight pieces per thread and phase
+    constexpr int WSLAB = NW * NT;                     // pieces per weight buffer (rounded up: every thread loads and stores NW, unconditionally)
+    const int left = TR ? 1 : dil * (KW - 1) / 2;
+    const int span = TR ? 1 : dil * (KW - 1);
+    const int xw = XT + span;                          // window index i <-> time q0 - left + i
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* ws = (u32x4*)smem;                          // [2 buffers][TG][3][2 octets][VR]
+    u32x4* xs = ws + 2 * WSLAB;                        // [3][2 octets][xw]
+
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * VR;
+    const int q0 = blockIdx.x * XT;
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_all & 3, rg = wave_all >> 2;  // column group (64 time steps), row group (32 RT rows)
+    const int r32 = lane & 31, h = lane >> 5;
+    const int lin = len_in ? min(len_in[b], T_in) : T_in;
+    const float* inb = in + (size_t)b * Cin * T_in;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)min((size_t)Cin * T_in * 4, (size_t)0x7fffffff), 0x00020000);
+    const int n_chunks = (Cin + 15) >> 4;
+
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xreg[NIT][8];
+    u32x4 wreg[NW];
+    // ---- input window, item (o, t) = 8 channels c0 + 8 o .. at window column t (consecutive lanes = consecutive columns of one octet:
+    // every load instruction reads one 256-byte run of a channel row, every store 1 KiB contiguous)
+    auto load_x = [&](int ch) {
+        const int c0 = ch * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * NT;
+            const int o = idx >= xw, t = idx - o * xw;
+            const int time = q0 - left + t;
+            const bool tin = t < xw && time >= 0 && time < lin;
+            // no branches: an element outside the window / the row / the channels is a load past num_records, which returns zero
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 8 * o + j;
+                const unsigned off = (tin && c < Cin) ? (unsigned)(c * T_in + time) * 4u : 0x80000000u;
+                xreg[it][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, (int)off, 0, 0));
+            }
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * NT;
+            const int o = idx >= xw, t = idx - o * xw;
+            if (t < xw) {
+                u32x4 wh, wm, wl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hh, mm, ll;
+                    lrelu_split3_pair(xreg[it][2 * j], xreg[it][2 * j + 1], pre_slope, hh, mm, ll);
+                    wh[j] = hh; wm[j] = mm; wl[j] = ll;
+                }
+                xs[(0 * 2 + o) * xw + t] = wh;
+                xs[(1 * 2 + o) * xw + t] = wm;
+                xs[(2 * 2 + o) * xw + t] = wl;
+            }
+        }
+    };
+    // ---- weight slab of taps g0 .. g0 + tg of chunk ch: [tap][piece][octet][row] <- Wb[ch][kw][piece][octet][r0 + row]  (16-byte pieces)
+    auto load_w = [&](int ch, int g0, int tg) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = min((int)threadIdx.x + i * NT, tg * 3 * VR * 2 - 1);  // past the group: a harmless duplicate of its last element
+            const int row = idx % VR, ko = idx / VR;                               // ko = (tap_local * 3 + piece) * 2 + octet
+            wreg[i] = Wb[(((size_t)ch * KW + g0) * 3 * 2 + ko) * rows_pad + r0 + row];
+        }
+    };
+    auto store_w = [&](int buf, int tg) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) ws[buf * WSLAB + threadIdx.x + i * NT] = wreg[i];
+        (void)tg;
+    };
+
+    load_x(0);
+    load_w(0, 0, KW < TG ? KW : TG);
+    store_x();
+    store_w(0, KW < TG ? KW : TG);
+    int p = 0;                                         // phase counter (weight buffer parity)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+#pragma unroll
+        for (int gi = 0; gi < NPH; ++gi, ++p) {
+            const int g0 = gi * TG;
+            const int tg = (KW - g0) < TG ? (KW - g0) : TG;                        // compile-time after unrolling
+            const int g0n = gi + 1 < NPH ? g0 + TG : 0;
+            const int tgn = (KW - g0n) < TG ? (KW - g0n) : TG;
+            const int chn = gi + 1 < NPH ? ch : ch + 1;
+            __syncthreads();                           // phase p - 1 is over everywhere: its weight buffer and (at a chunk boundary) xs are free
+            if (gi == 0 && ch > 0) {
+                store_x();                             // the window of this chunk, loaded during the previous chunk's last phase
+                __syncthreads();
+            }
+            if (chn < n_chunks) load_w(chn, g0n, tgn);
+            if (gi == NPH - 1 && ch + 1 < n_chunks) load_x(ch + 1);
+            const u32x4* wb = ws + (p & 1) * WSLAB;
+#pragma unroll(KW <= 3 ? 3 : 1)
+            for (int lk = 0; lk < tg; ++lk) {
+                const int kw = g0 + lk;
+                const int off = TR ? (left - kw) : kw * dil;                       // window column = local time + off
+                bf16x8 a[RT][3], x[2][3];
+#pragma unroll
+                for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) a[ri][pc] = __builtin_bit_cast(bf16x8, wb[((lk * 3 + pc) * 2 + h) * VR + (rg * RT + ri) * 32 + r32]);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) x[ti][pc] = __builtin_bit_cast(bf16x8, xs[(pc * 2 + h) * xw + wave * 64 + ti * 32 + r32 + off]);
+                // six piece products, smallest first; the (row tile, time tile) accumulators alternate inside a term
+#define VV_X3_TERM(pa, pb)                                                                                                   \
+    _Pragma("unroll") for (int ri = 0; ri < RT; ++ri) _Pragma("unroll") for (int ti = 0; ti < 2; ++ti)                         \
+        acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ri][pa], x[ti][pb], acc[ri][ti], 0, 0, 0)
+                VV_X3_TERM(0, 2); VV_X3_TERM(2, 0); VV_X3_TERM(1, 1); VV_X3_TERM(0, 1); VV_X3_TERM(1, 0); VV_X3_TERM(0, 0);
+#undef VV_X3_TERM
+            }
+            if (chn < n_chunks) store_w((p + 1) & 1, tgn);
+        }
+    }
+
+    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32]
+    float* outb = out + (size_t)b * Cout * T_out;
+    const float* resb = resid ? resid + (size_t)b * Cout * T_out : nullptr;
+#pragma unroll
+    for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int q = q0 + wave * 64 + ti * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + (rg * RT + ri) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= rows_total) continue;
+                int co, t;
+                if (TR) { co = row / up; t = q * up + (row - co * up) - up / 2; }
+                else { co = row; t = q; }
+                if (t < 0 || t >= T_out) continue;
+                float v = acc[ri][ti][r] + bias[co];
+                const size_t o = (size_t)co * T_out + t;
+                if (resb) v += resb[o];
+                v *= out_scale;
+                if (accumulate) v += outb[o];
+                outb[o] = v;
+            }
+        }
+}
+
+struct X3Setup {                                       // dynamic LDS above 64 KiB needs the attribute once per kernel and device
+    std::mutex mu;
+    std::atomic<unsigned long long> done{0};
+    hipError_t ensure(const void* kern, int lds) {
+        int dev = 0;
+        if (hipError_t he = hipGetDevice(&dev); he != hipSuccess) return he;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!(done.load(std::memory_order_acquire) >> dev & 1)) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!(done.load(std::memory_order_relaxed) >> dev & 1)) {
+                if (hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); he != hipSuccess) return he;
+                done.fetch_or(1ull << dev, std::memory_order_release);
+            }
+        }
+        return hipSuccess;
+    }
+};
+
+template <int KW, bool TR, int RT, int TG, int NWV>
+hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
+    constexpr int NT = 64 * NWV, VR = (NWV / 4) * RT * 32;
+    constexpr int WSLAB = (TG * 3 * VR * 2 + NT - 1) / NT * NT;
+    const size_t lds_max = (size_t)(3 * (XT + (TR ? 1 : 5 * (KW - 1))) * 2 + 2 * WSLAB) * 16;      // the attribute is set for the largest dilation
+    const size_t lds = (size_t)(3 * (XT + (TR ? 1 : a->dil * (KW - 1))) * 2 + 2 * WSLAB) * 16;
+    static X3Setup setup;
+    auto kern = conv_x3_kernel<KW, TR, RT, TG, NWV>;
+    if (hipError_t he = setup.ensure((const void*)kern, (int)lds_max); he != hipSuccess) return he;
+    const int q_total = TR ? a->T_in + 1 : a->T_out;
+    dim3 grid((q_total + XT - 1) / XT, (a->rows_total + VR - 1) / VR, a->B);
+    kern<<<grid, NT, lds, st>>>(a->in, (const u32x4*)a->W_x3, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad, a->T_in, a->T_out,
+                                a->Cout, a->dil, a->up, a->pre_slope, a->out_scale, a->accumulate, a->len_in);
+    return hipGetLastError();
+}
+template <int KW, bool TR>
+hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
+    if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
+    if (a->rows_total <= 64 || a->wg_rows == 64) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4>(a, st);
+    return launch_x3_t<KW, TR, 2, 2, 8>(a, st);                                // 128 rows per workgroup, 8 waves
+}
+
+}  // namespace
+
+size_t vvk_conv_split_bytes(int Cin_pad, int KW, int rows_pad) { return (size_t)((Cin_pad + 15) / 16) * KW * 3 * rows_pad * 16 * 2; }
+
+int vvk_conv_split_weights(const float* Wt, int Cin_pad, int KW, int rows_pad, void* Wb, hipStream_t st, const char** err) {
+    if (!Wt || !Wb || Cin_pad < 1 || KW < 1 || rows_pad < 1 || rows_pad % 64 || ((uintptr_t)Wb % 16)) { *err = "conv_split_weights: bad arguments"; return -22; }
+    const int chunks = (Cin_pad + 15) / 16;
+    const size_t n = (size_t)chunks * KW * rows_pad * 16;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    split_weights_kernel<<<grid, 256, 0, st>>>(Wt, (uint16_t*)Wb, Cin_pad, KW, rows_pad, chunks);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}
+
+// Same contract as vvk_conv (shapes already validated there); a->W_x3 = the split slab of a->W.
+int vvk_conv_x3(const vv_conv_args* a, hipStream_t st, const char** err) {
+    if (!a->W_x3 || ((uintptr_t)a->W_x3 % 16)) { *err = "conv: split weight slab missing or misaligned"; return -22; }
+    hipError_t he = hipSuccess;
+    if (a->transposed) {
+        he = launch_x3<2, true>(a, st);
+    } else {
+        switch (a->KW) {
+            case 3: he = launch_x3<3, false>(a, st); break;
+            case 7: he = launch_x3<7, false>(a, st); break;
+            case 11: he = launch_x3<11, false>(a, st); break;
+            default: *err = "conv: kernel width must be 3, 7 or 11"; return -22;
+        }
+    }
+    if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
+    return 0;
+}

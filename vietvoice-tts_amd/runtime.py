@@ -80,7 +80,7 @@ class vv_conv_args(C.Structure):
                 ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("T_in", C.c_int32), ("T_out", C.c_int32),
                 ("KW", C.c_int32), ("dil", C.c_int32), ("transposed", C.c_int32), ("up", C.c_int32),
                 ("rows_total", C.c_int32), ("rows_pad", C.c_int32), ("accumulate", C.c_int32),
-                ("pre_slope", C.c_float), ("out_scale", C.c_float), ("len_in", C.c_void_p)]
+                ("pre_slope", C.c_float), ("out_scale", C.c_float), ("len_in", C.c_void_p), ("W_x3", C.c_void_p), ("wg_rows", C.c_int32)]
 
 
 class vv_mrf_args(C.Structure):
@@ -125,6 +125,8 @@ EXPORTS = {
     "vv_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                C.c_int, C.c_void_p]),
     "vv_rope_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_conv_split_bytes": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
+    "vv_conv_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vv_gemm_tail_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vv_rope_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
