@@ -218,7 +218,7 @@ typedef struct vv_conv_args {
     const void* W_x3;         /* optional: W split by vv_conv_split_weights; when given, the products run as exact 3-way bf16
                                  splits on the bf16 matrix pipe (six piece products, fp32 accumulate: fp32 fidelity, ~2.7x less
                                  matrix time) instead of v_mfma_f32_32x32x2_f32.  Same result class, not bit-identical. */
-    int32_t wg_rows;          /* x3 only: 0 = auto (128-row workgroups of 8 waves when rows_total > 64), 64 = force the 4-wave form */
+    int32_t wg_rows;          /* x3 only: 0 = default (64-row workgroups of 4 waves), 128 = 128-row workgroups of 8 waves when rows_total > 64 */
 } vv_conv_args;
 int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
 /* W fp32 [Cin_pad][KW][rows_pad] -> out [ceil(Cin_pad / 16)][KW][3 pieces][2 octets][rows_pad][8] bf16 (w = h + m + l exactly, each piece the

@@ -524,13 +524,13 @@ def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pr
     if x3:
         wb = _split_conv_weights(eng, rt, gu, dw)
         a.W_x3 = wb.data_ptr()
-        a.wg_rows = x3 if (isinstance(x3, int) and not isinstance(x3, bool)) else 0      # 64: the 4-wave workgroup form
+        a.wg_rows = x3 if (isinstance(x3, int) and not isinstance(x3, bool)) else 0      # 128: the 8-wave workgroup form
     gu.check(eng, eng.lib.vv_conv1d(eng.ctx, C.byref(a), gu.stream()))
     torch.cuda.synchronize()
     return out
 
 
-@pytest.mark.parametrize("x3", [False, True, 64])         # f32 MFMA / x3 (8-wave workgroups for > 64 rows) / x3 forced to 4-wave workgroups
+@pytest.mark.parametrize("x3", [False, True, 128])         # f32 MFMA / x3 (4-wave workgroups) / x3 with 8-wave 128-row workgroups
 @pytest.mark.parametrize("KW,dil", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5), (7, 1)])
 @pytest.mark.parametrize("cin,cout,T", [(20, 24, 300), (64, 64, 517), (100, 128, 40)])
 def test_conv1d_mfma(hip_tiny, KW, dil, cin, cout, T, x3):
@@ -638,7 +638,7 @@ def test_conv1d_length_mask(hip_tiny, x3):
         assert gu.rel_err(got[i:i + 1, :, :L], ref) < TOL_F32
 
 
-@pytest.mark.parametrize("x3", [False, True, 64])
+@pytest.mark.parametrize("x3", [False, True, 128])
 @pytest.mark.parametrize("u,cin,cout,T", [(8, 32, 16, 70), (2, 16, 8, 300), (8, 64, 32, 257), (2, 128, 64, 40)])
 def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T, x3):
     rt, gu = _imports()

@@ -53,6 +53,7 @@ struct vv_ctx {
     int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
                                         // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
                                         // context: 1, fp32 context: 0 -- the numerics configuration stays on the f32 instruction)
+    int voc_x3_rows = 0;                // x3 workgroup rows for stages with > 64 rows: 0 = default (64, 4 waves), 128 = 8-wave workgroups
     char* x3_buf = nullptr;             // split weight slabs of every vocoder conv (built by vv_finalize_weights)
     std::map<std::string, const void*> x3_w;
     int fuse_mrf = 2;                   // K12 fused MRF pairs (C <= 64 stages): 0 never, 1 always, 2 auto = for decodes of <= 8 items
@@ -642,7 +643,7 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
         if (x3) {
             auto it = c->x3_w.find(name + ".weight");
             if (it == c->x3_w.end()) return c->fail(-2, "split weights of %s missing", name.c_str());
-            a.W_x3 = it->second;
+            a.W_x3 = it->second; a.wg_rows = c->voc_x3_rows;
         }
         a.B = B; a.Cin = Cin; a.Cout = Cout; a.T_in = T_in; a.T_out = T_out; a.KW = KW; a.dil = dil; a.transposed = up > 0; a.up = up;
         a.rows_total = up > 0 ? Cout * up : Cout; a.rows_pad = pad_to(a.rows_total, 64); a.accumulate = accumulate;
@@ -710,6 +711,10 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
     if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
+    if (!strcmp(name, "voc_x3_rows")) {
+        if (value != 0 && value != 128) return c->fail(-22, "vv_set_option: voc_x3_rows takes 0 (64-row workgroups) or 128");
+        c->voc_x3_rows = value; return 0;
+    }
     if (!strcmp(name, "voc_x3")) {
         if (value < -1 || value > 1) return c->fail(-22, "vv_set_option: voc_x3 takes -1 (by acoustic dtype), 0 (f32 MFMA) or 1 (3-way bf16 split)");
         c->voc_x3 = value; return 0;

@@ -238,30 +238,54 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, RT 
         }
     }
 
-    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32]
-    float* outb = out + (size_t)b * Cout * T_out;
-    const float* resb = resid ? resid + (size_t)b * Cout * T_out : nullptr;
+    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32].  Branch-free and batched: an element outside the
+    // rows / the time range carries an offset past num_records (loads return zero, stores are dropped), so the 16 residual loads
+    // and the 16 accumulate loads of a tile are all in flight together (the K11 form -- a bounds branch, a dependent load and a
+    // full wait per element -- cost up to a third of the launch here, where no MFMA backlog hides it).
+    const size_t out_elems = (size_t)Cout * T_out;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)b * out_elems), 0, (int)min(out_elems * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)((resid ? resid : out) + (size_t)b * out_elems), 0, (int)min(out_elems * 4, (size_t)0x7fffffff), 0x00020000);
 #pragma unroll
-    for (int ri = 0; ri < RT; ++ri)
+    for (int ri = 0; ri < RT; ++ri) {
+        float bv[16];
+        int cor[16], tph[16];                          // output channel, and (transposed) the phase term of the output time
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + (rg * RT + ri) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int co = row, ph = 0;
+            if (TR) { co = row / up; ph = (row - co * up) - up / 2; }
+            cor[r] = row < rows_total ? co : -1;
+            tph[r] = ph;
+            bv[r] = bias[min(co, Cout - 1)];
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int q = q0 + wave * 64 + ti * 32 + r32;
+            unsigned off[16];
+            float rv[16], ov[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = r0 + (rg * RT + ri) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= rows_total) continue;
-                int co, t;
-                if (TR) { co = row / up; t = q * up + (row - co * up) - up / 2; }
-                else { co = row; t = q; }
-                if (t < 0 || t >= T_out) continue;
-                float v = acc[ri][ti][r] + bias[co];
-                const size_t o = (size_t)co * T_out + t;
-                if (resb) v += resb[o];
+                const int t = TR ? q * up + tph[r] : q;
+                off[r] = (cor[r] >= 0 && t >= 0 && t < T_out) ? (unsigned)(cor[r] * T_out + t) * 4u : 0x80000000u;
+            }
+            if (resid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)off[r], 0, 0));
+            }
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ov[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, (int)off[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[ri][ti][r] + bv[r];
+                if (resid) v += rv[r];
                 v *= out_scale;
-                if (accumulate) v += outb[o];
-                outb[o] = v;
+                if (accumulate) v += ov[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, (int)off[r], 0, 0);
             }
         }
+    }
 }
 
 struct X3Setup {                                       // dynamic LDS above 64 KiB needs the attribute once per kernel and device
@@ -300,8 +324,10 @@ hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
 template <int KW, bool TR>
 hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
     if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
-    if (a->rows_total <= 64 || a->wg_rows == 64) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4>(a, st);
-    return launch_x3_t<KW, TR, 2, 2, 8>(a, st);                                // 128 rows per workgroup, 8 waves
+    // 64-row workgroups of 4 waves by default: 128-row workgroups of 8 waves (the window split once for twice the rows) are 1-3 %
+    // faster per launch on the k = 3 shapes but 1.2 % slower in the decode (one resident workgroup per CU: nothing overlaps its epilogue)
+    if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4>(a, st);
+    return launch_x3_t<KW, TR, 2, 2, 8>(a, st);
 }
 
 }  // namespace
