@@ -225,9 +225,12 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
+    voc_x3 = a.dtype == "bf16"                       # the bf16 context's default (vv_set_option "voc_x3" -1): vocoder products as 3-way bf16 splits
     for opt in [o for o in os.environ.get("VV_BENCH_OPTIONS", "").split(",") if o]:      # A/B switches of the C ABI, e.g. rope_rows=0
         k, _, v = opt.partition("=")
         eng.set_option(k, int(v))
+        if k == "voc_x3" and int(v) >= 0:
+            voc_x3 = int(v) == 1
     if os.environ.get("VV_BENCH_DUMP_MAPS"):          # diagnostics for profiler-side crashes: the loaded images, so a raw stack can be symbolised
         with open("/proc/self/maps") as src, open(os.environ["VV_BENCH_DUMP_MAPS"], "w") as dst:
             dst.write(src.read())
@@ -327,7 +330,10 @@ def main():
     other_rooflines = {"attention (K8, bf16 MFMA)": _rf("attention", "mfma", peak),
                        "layernorm+residual (K4)": _rf("norm", "hbm", HBM_PEAK_GBS),
                        "pos-conv (K3, bf16 MFMA)": _rf("posconv", "mfma", peak),
-                       "vocoder convs (K11/K12, f32 MFMA)": _rf("voc_conv", "mfma", MFMA_F32_PEAK_TFLOPS),
+                       # x3: six bf16 piece products per fp32 product, so the matrix roof for ALGORITHMIC flops is the bf16 peak / 6
+                       ("vocoder convs (K11x: fp32 products as six bf16 MFMA terms; roof = bf16 peak / 6)" if voc_x3 else "vocoder convs (K11/K12, f32 MFMA)"):
+                           _rf("voc_conv", "mfma", round(MFMA_BF16_PEAK_TFLOPS / 6, 1) if voc_x3 else MFMA_F32_PEAK_TFLOPS),
+                       "vocoder convs, HBM side (algorithmic bytes per launch)": _rf("voc_conv", "hbm", HBM_PEAK_GBS),
                        "vocoder conv_post+tanh+int16 (K13)": _rf("voc_post", "hbm", HBM_PEAK_GBS)}
     classes = {}
     for k, v in prof.items():
@@ -345,9 +351,12 @@ def main():
         "rtf": round(elapsed / total_audio, 6),
         "timed_region": ("inputs and PCM resident in HBM (--resident)" if a.resident else
                          "host (pinned) int16 clips / ids / noise -> H2D -> preprocess + Euler steps + vocoder -> int16 PCM D2H to pinned host memory (SURVEY 8d)"),
-        "hbm_target_note": "north_star's '>= 40 % of HBM roofline on the vocoder kernel' applies to the memory-bound vocoder kernels only (K13 conv_post+tanh+int16, "
-                           "K10 frame slice): in fp32 every MRF / upsample conv has arithmetic intensity 32-450 flop/B, above the f32 ridge (~20), and is reported "
-                           "against the 157.3 TFLOP/s f32 MFMA roof instead (SURVEY 7 / 8d)",
+        "hbm_target_note": "north_star's '>= 40 % of HBM roofline on the vocoder kernel' applies to the memory-bound vocoder kernels (K13 conv_post+tanh+int16, "
+                           "K10 frame slice): every MRF / upsample conv has arithmetic intensity 32-450 flop/B, above the f32-MFMA ridge (~20) and around the "
+                           "ridge of the six-term bf16 form (~52), and is reported against its matrix roof with the HBM side beside it (SURVEY 7 / 8d)",
+        "vocoder_arith": ("fp32 in / out / accumulate; every product a*w taken as the six bf16 piece products >= 2^-16 |a w| of exact 3-way splits a = h+m+l, "
+                          "w = h+m+l (v_mfma_f32_32x32x16_bf16, vv_vocoder_x3.hip): fp32 fidelity -- waveform max |err| vs the float64 oracle 7.6e-7 against "
+                          "7.4e-7 for v_mfma_f32_32x32x2_f32 (tests/test_fullsize_gpu.py)") if voc_x3 else "fp32 (v_mfma_f32_32x32x2_f32)",
         "config": {"workload": (f"batch={a.batch} per GPU, 256-token utterances (N=1600 frames, 11.061 s generated each), "
                                 if a.workload == "batch32" else
                                 f"mixed256: {nb} ragged units on this rank of {a.batch * world} (64-512 tokens, 3-9 s reference clips) in "

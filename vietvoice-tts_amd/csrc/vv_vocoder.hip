@@ -136,28 +136,70 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
         }
     }
 
-    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32]
-    float* outb = out + (size_t)b * Cout * T_out;
-    const float* resb = resid ? resid + (size_t)b * Cout * T_out : nullptr;
+    // ---- epilogue: D[row_local = (reg&3) + 8(reg>>2) + 4h][time_local = r32].  Branch-free and batched (as in vv_vocoder_x3.hip):
+    // an element outside the rows / the time range carries an offset past num_records (loads return zero, stores are dropped), so
+    // the residual and accumulate loads of a tile are all in flight together.  The arithmetic -- (acc + bias [+ resid]) * scale
+    // [+ out], separate roundings -- is unchanged: the bit-exact contract with mrf_pair_kernel holds.
+    const size_t out_elems = (size_t)Cout * T_out;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)b * out_elems), 0, (int)min(out_elems * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)((resid ? resid : out) + (size_t)b * out_elems), 0, (int)min(out_elems * 4, (size_t)0x7fffffff), 0x00020000);
+    if constexpr (TRANSPOSED) {                        // 4 launches per decode, and the phase arithmetic of a batch spills here: element-wise
+        float* outb = out + (size_t)b * Cout * T_out;
+#pragma unroll
+        for (int ri = 0; ri < RT; ++ri)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int q = q0 + wave * 64 + ti * 32 + r32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= rows_total) continue;
+                    const int co = row / up, t = q * up + (row - co * up) - up / 2;
+                    if (t < 0 || t >= T_out) continue;
+                    float v = acc[ri][ti][r] + bias[co];
+                    const size_t o = (size_t)co * T_out + t;
+                    if (resid) v += resid[(size_t)b * out_elems + o];
+                    v *= out_scale;
+                    if (accumulate) v += outb[o];
+                    outb[o] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int q = q0 + wave * 64 + ti * 32 + r32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = r0 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= rows_total) continue;
-                int co, t;
-                if (TRANSPOSED) { co = row / up; t = q * up + (row - co * up) - up / 2; }
-                else { co = row; t = q; }
-                if (t < 0 || t >= T_out) continue;
-                float v = acc[ri][ti][r] + bias[co];
-                const size_t o = (size_t)co * T_out + t;
-                if (resb) v += resb[o];
-                v *= out_scale;
-                if (accumulate) v += outb[o];
-                outb[o] = v;
+            for (int rh = 0; rh < 16; rh += 4) {       // four accumulator registers at a time: this kernel hides latency by occupancy (<= 106 VGPRs)
+                unsigned off[4];
+                float bv[4], rv[4], ov[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = rh + k;
+                    const int row = r0 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    int co = row, t = q;
+                    if (TRANSPOSED) { co = row / up; t = q * up + (row - co * up) - up / 2; }
+                    off[k] = (row < rows_total && t >= 0 && t < T_out) ? (unsigned)(co * T_out + t) * 4u : 0x80000000u;
+                    bv[k] = bias[min(co, Cout - 1)];
+                }
+                if (resid) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)off[k], 0, 0));
+                }
+                if (accumulate) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ov[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, (int)off[k], 0, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc[ri][ti][rh + k] + bv[k];
+                    if (resid) v += rv[k];
+                    v *= out_scale;
+                    if (accumulate) v += ov[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, (int)off[k], 0, 0);
+                }
             }
         }
 }
