@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // registers before the MFMA block of chunk c's last phase and split / stored behind the next barrier (+ one barrier to publish).
 // NWV: waves per workgroup, 4 (one row group) or 8 (two row groups of 32 RT rows sharing the staged window: the window is
 // loaded and split once for 64 RT rows -- the stages with >= 128 rows).
-template <int KW, bool TR, int RT, int TG, int NWV>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, RT == 1 ? 3 : 2))) void conv_x3_kernel(const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias,
+template <int KW, bool TR, int RT, int TG, int NWV, int OCC>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_x3_kernel(const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias,
                                                          float* __restrict__ out, const float* __restrict__ resid, int Cin, int rows_total,
                                                          int rows_pad, int T_in, int T_out, int Cout, int dil, int up, float pre_slope,
                                                          float out_scale, int accumulate, const int* __restrict__ len_in) {
@@ -306,14 +306,14 @@ struct X3Setup {                                       // dynamic LDS above 64 K
     }
 };
 
-template <int KW, bool TR, int RT, int TG, int NWV>
+template <int KW, bool TR, int RT, int TG, int NWV, int OCC>
 hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
     constexpr int NT = 64 * NWV, VR = (NWV / 4) * RT * 32;
     constexpr int WSLAB = (TG * 3 * VR * 2 + NT - 1) / NT * NT;
     const size_t lds_max = (size_t)(3 * (XT + (TR ? 1 : 5 * (KW - 1))) * 2 + 2 * WSLAB) * 16;      // the attribute is set for the largest dilation
     const size_t lds = (size_t)(3 * (XT + (TR ? 1 : a->dil * (KW - 1))) * 2 + 2 * WSLAB) * 16;
     static X3Setup setup;
-    auto kern = conv_x3_kernel<KW, TR, RT, TG, NWV>;
+    auto kern = conv_x3_kernel<KW, TR, RT, TG, NWV, OCC>;
     if (hipError_t he = setup.ensure((const void*)kern, (int)lds_max); he != hipSuccess) return he;
     const int q_total = TR ? a->T_in + 1 : a->T_out;
     dim3 grid((q_total + XT - 1) / XT, (a->rows_total + VR - 1) / VR, a->B);
@@ -323,11 +323,13 @@ hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
 }
 template <int KW, bool TR>
 hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
-    if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
+    if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4, 3>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
     // 64-row workgroups of 4 waves by default: 128-row workgroups of 8 waves (the window split once for twice the rows) are 1-3 %
     // faster per launch on the k = 3 shapes but 1.2 % slower in the decode (one resident workgroup per CU: nothing overlaps its epilogue)
-    if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4>(a, st);
-    return launch_x3_t<KW, TR, 2, 2, 8>(a, st);
+    // (3 workgroups per CU -- 2 taps per phase, <= 168 VGPRs -- was measured per launch: k = 7 and the transposed form 7-10 % faster,
+    // k = 3 / 11 20-50 % slower from spills; about 3 ms of the decode in all, not taken: profiles/r02/voc_x3_conv_shapes_occ3.txt)
+    if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4, 2>(a, st);
+    return launch_x3_t<KW, TR, 2, 2, 8, 2>(a, st);
 }
 
 }  // namespace
