@@ -507,6 +507,10 @@ int launch_conv(const vv_conv_args* a, hipStream_t st) {
 int vvk_conv(const vv_conv_args* a, hipStream_t st, const char** err) {
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->T_in <= 0 || a->T_out <= 0) { *err = "conv: empty shape"; return -22; }
     if (!(a->pre_slope > 0.f && a->pre_slope <= 1.f)) { *err = "conv: pre_slope must be in (0, 1] (1 = no activation)"; return -22; }
+    // input windows and output tiles are addressed through buffer resources with 32-bit byte offsets (out-of-range = dropped)
+    if ((size_t)a->Cin * a->T_in * 4 >= ((size_t)1 << 31) || (size_t)a->Cout * a->T_out * 4 >= ((size_t)1 << 31)) {
+        *err = "conv: a [C][T] slab of one item reaches 2 GiB; decode fewer frames per call"; return -22;
+    }
     if (a->rows_pad % 64 || a->rows_pad < a->rows_total || ((uintptr_t)a->W % 16)) { *err = "conv: weight slab must be padded to 64 rows and 16-byte aligned"; return -22; }
     if (a->transposed) {
         if (a->KW != 2 || a->up < 2 || (a->up & 1) || a->rows_total != a->Cout * a->up || a->T_out != a->T_in * a->up) {
