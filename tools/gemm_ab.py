@@ -19,7 +19,10 @@ for p in libs:
     engs.append(rt.HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4))
 M = 102400
 g = torch.Generator().manual_seed(0)
-shapes = [("qkv_rope", 1, 3072, 1024, 0), ("qkv_rope_rows", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0)]
+shapes = [("qkv_rope", 1, 3072, 1024, 0), ("qkv_rope_rows", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0),
+          # epilogue-cost probes (only with GEMM_AB_SHAPES): the QKV / FF1 shapes with the plain store epilogue
+          ("qkv_plain_store", 0, 3072, 1024, 0), ("ff1_plain_store", 0, 2048, 1024, 0),
+          ("qkv_rope_off_probe", 1, 3072, 1024, 0)]      # the rope-mode kernel with rope_dim = 0: every tile takes its plain store path
 cs = torch.rand(1600, 64, device=dev)
 pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
 cs_rows = cs[pos.long()].contiguous()            # what vv_rope_rows builds once per call
@@ -27,7 +30,7 @@ st = torch.cuda.current_stream().cuda_stream
 tot = {p: 0.0 for p in libs}
 only = [x for x in os.environ.get("GEMM_AB_SHAPES", "").split(",") if x]      # e.g. the four shapes of one DiT block for a PMC pass
 for name, mode, N, K, act in shapes:
-    if only and name not in only:
+    if (only and name not in only) or (not only and (name.endswith("_plain_store") or name.endswith("_probe"))):
         continue
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
@@ -41,7 +44,7 @@ for name, mode, N, K, act in shapes:
         a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K
         a.bias, a.gate = bias.data_ptr(), (gate.data_ptr() if mode == 3 else None)
         if mode == 1:
-            a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
+            a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, (0 if name.endswith("_off_probe") else 1024)
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr(); a.rope_pos = pos.data_ptr()
             if name.endswith("_rows") and hasattr(a, "rope_by_row"):
                 a.rope_cs_q = a.rope_cs_k = cs_rows.data_ptr(); a.rope_by_row = 1
