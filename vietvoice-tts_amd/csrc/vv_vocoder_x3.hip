@@ -326,8 +326,9 @@ hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
     if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4, 3>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
     // 64-row workgroups of 4 waves by default: 128-row workgroups of 8 waves (the window split once for twice the rows) are 1-3 %
     // faster per launch on the k = 3 shapes but 1.2 % slower in the decode (one resident workgroup per CU: nothing overlaps its epilogue)
-    // (3 workgroups per CU -- 2 taps per phase, <= 168 VGPRs -- was measured per launch: k = 7 and the transposed form 7-10 % faster,
-    // k = 3 / 11 20-50 % slower from spills; about 3 ms of the decode in all, not taken: profiles/r02/voc_x3_conv_shapes_occ3.txt)
+    // 3 workgroups per CU (2 taps per phase, <= 168 VGPRs) where the kernel fits without spilling: k = 7 and the transposed form are
+    // 7-10 % faster per launch (1.4 ms of the 112 ms decode class); k = 3 / 11 spill and are 20-50 % slower (profiles/r02/voc_x3_conv_shapes_occ3.txt)
+    if (a->wg_rows != 128 && (KW == 7 || TR)) return launch_x3_t<KW, TR, 2, 2, 4, 3>(a, st);
     if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4, 2>(a, st);
     return launch_x3_t<KW, TR, 2, 2, 8, 2>(a, st);
 }
