@@ -104,7 +104,7 @@ template <int KW, bool TR, int RT, int TG, int NWV, int OCC>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void conv_x3_kernel(const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias,
                                                          float* __restrict__ out, const float* __restrict__ resid, int Cin, int rows_total,
                                                          int rows_pad, int T_in, int T_out, int Cout, int dil, int up, float pre_slope,
-                                                         float out_scale, int accumulate, const int* __restrict__ len_in) {
+                                                         float out_scale, int accumulate, const int* __restrict__ len_in, int n_tt, int n_rt, int n_win) {
     constexpr int NT = 64 * NWV;                       // threads
     constexpr int VR = (NWV / 4) * RT * 32;            // rows per workgroup
     constexpr int NIT = (2 * (XT + 50) + NT - 1) / NT; // window items (time, channel octet) per thread: 2 (256 + span), span <= 50
@@ -118,9 +118,16 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, O
     u32x4* ws = (u32x4*)smem;                          // [2 buffers][TG][3][2 octets][VR]
     u32x4* xs = ws + 2 * WSLAB;                        // [3][2 octets][xw]
 
-    const int b = blockIdx.z;
-    const int r0 = blockIdx.y * VR;
-    const int q0 = blockIdx.x * XT;
+    // Workgroup -> (window = (item, time tile), row tile), XCD-aware: the row tiles of one window all read the same input window, so
+    // they are given ids 8 apart -- the same XCD (workgroups are dealt round-robin over the 8 XCDs by id), dispatched back to back --
+    // and the window comes out of that XCD's L2 instead of being fetched from HBM once per row tile (measured before: 2x the
+    // algorithmic reads at 2 row tiles, 5x at 4, up to 20x for the transposed convs: profiles/r02/voc_conv_pmc_traffic*.txt).
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int win = (jj / n_rt) * 8 + xcd;
+    if (win >= n_win) return;
+    const int b = win / n_tt;
+    const int r0 = (jj % n_rt) * VR;
+    const int q0 = (win % n_tt) * XT;
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = wave_all & 3, rg = wave_all >> 2;  // column group (64 time steps), row group (32 RT rows)
@@ -316,9 +323,12 @@ hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
     auto kern = conv_x3_kernel<KW, TR, RT, TG, NWV, OCC>;
     if (hipError_t he = setup.ensure((const void*)kern, (int)lds_max); he != hipSuccess) return he;
     const int q_total = TR ? a->T_in + 1 : a->T_out;
-    dim3 grid((q_total + XT - 1) / XT, (a->rows_total + VR - 1) / VR, a->B);
-    kern<<<grid, NT, lds, st>>>(a->in, (const u32x4*)a->W_x3, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad, a->T_in, a->T_out,
-                                a->Cout, a->dil, a->up, a->pre_slope, a->out_scale, a->accumulate, a->len_in);
+    const int n_tt = (q_total + XT - 1) / XT, n_rt = (a->rows_total + VR - 1) / VR;
+    const long long wins8 = ((long long)n_tt * a->B + 7) / 8;
+    if (wins8 * 8 * n_rt > 0x7fffffffLL) return hipErrorInvalidValue;
+    kern<<<dim3((unsigned)(wins8 * 8 * n_rt)), NT, lds, st>>>(a->in, (const u32x4*)a->W_x3, a->bias, a->out, a->resid, a->Cin, a->rows_total, a->rows_pad,   // 1-D walk, id % 8 = XCD group
+                                                              a->T_in, a->T_out, a->Cout, a->dil, a->up, a->pre_slope, a->out_scale, a->accumulate, a->len_in,
+                                                              n_tt, n_rt, n_tt * a->B);
     return hipGetLastError();
 }
 template <int KW, bool TR>
