@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, O
     store_w(0, KW < TG ? KW : TG);
     int p = 0;                                         // phase counter (weight buffer parity)
     for (int ch = 0; ch < n_chunks; ++ch) {
-#pragma unroll
+#pragma unroll(OCC == 3 && KW > 7 ? 1 : NPH)
         for (int gi = 0; gi < NPH; ++gi, ++p) {
             const int g0 = gi * TG;
             const int tg = (KW - g0) < TG ? (KW - g0) : TG;                        // compile-time after unrolling
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, O
             if (chn < n_chunks) load_w(chn, g0n, tgn);
             if (gi == NPH - 1 && ch + 1 < n_chunks) load_x(ch + 1);
             const u32x4* wb = ws + (p & 1) * WSLAB;
-#pragma unroll(KW <= 3 ? 3 : 1)
+#pragma unroll(KW <= 3 && OCC < 3 ? 3 : 1)
             for (int lk = 0; lk < tg; ++lk) {
                 const int kw = g0 + lk;
                 const int off = TR ? (left - kw) : kw * dil;                       // window column = local time + off
@@ -336,9 +336,10 @@ hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
     if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4, 3>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
     // 64-row workgroups of 4 waves by default: 128-row workgroups of 8 waves (the window split once for twice the rows) are 1-3 %
     // faster per launch on the k = 3 shapes but 1.2 % slower in the decode (one resident workgroup per CU: nothing overlaps its epilogue)
-    // 3 workgroups per CU (2 taps per phase, <= 168 VGPRs) where the kernel fits without spilling: k = 7 and the transposed form are
-    // 7-10 % faster per launch (1.4 ms of the 112 ms decode class); k = 3 / 11 spill and are 20-50 % slower (profiles/r02/voc_x3_conv_shapes_occ3.txt)
-    if (a->wg_rows != 128 && (KW == 7 || TR)) return launch_x3_t<KW, TR, 2, 2, 4, 3>(a, st);
+    // 3 workgroups per CU (2 taps per phase, <= 168 VGPRs, taps not unrolled) where the kernel fits with at most a few spilled dwords:
+    // k = 3, k = 7 and the transposed form are 4-11 % faster per launch; k = 11 keeps 2 workgroups per CU and 4 taps per phase (at 168
+    // VGPRs it spills 21-65 dwords and is 10 % slower): profiles/r02/voc_x3_conv_shapes_occ3*.txt
+    if (a->wg_rows != 128 && (KW <= 7 || TR)) return launch_x3_t<KW, TR, 2, 2, 4, 3>(a, st);
     if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4, 2>(a, st);
     return launch_x3_t<KW, TR, 2, 2, 8, 2>(a, st);
 }
