@@ -100,6 +100,65 @@ def test_batching_frontend_batch_composition_invariance(tmp_path):
         e.cleanup()
 
 
+def test_engine_outputs_match_the_engine_on_oracle_sessions(tmp_path):
+    """a5 / N4 / N2 against the ORACLE rather than against another HIP run.  The same TTSEngine class driven by oracle sessions (CPU
+    fp32 restatement, the reference's one-chunk-at-a-time session pattern) and by the HIP path from the same seed -- same chunk plan,
+    same noise stream -- must give the same PCM within the fp32 tolerance of the e2e tests (+-2 LSB): (a5) all chunks as one ragged
+    GPU batch, (N4) streamed one chunk per wave, (N2) a request through the batching front end, whose noise stream is seeded by
+    (random_seed, serial): the oracle is fed the same blocks chunk by chunk and its waves are joined by the same cross-fade."""
+    import torch
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    from oracle.vv_oracle import Oracle, OracleSession
+    holder = {}
+
+    def factory(spec, weights, config):
+        holder["oracle"] = Oracle(spec, weights, nfe_step=config.nfe_step)
+        return {k: OracleSession(holder["oracle"], k, seed=config.random_seed) for k in ("preprocess", "transformer", "decode")}
+    cfg = ModelConfig(model_cache_dir=str(tmp_path), synthetic_model=True, model_spec="tiny", nfe_step=5, acoustic_dtype="fp32", max_chunk_duration=8.0)
+    ora = TTSEngine(cfg, session_factory=factory)
+    want, _ = ora.synthesize(LONG)
+
+    def close(a, b):
+        assert a.shape == b.shape, (a.shape, b.shape)
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert int(d.max()) <= 2 and float((d > 1).mean()) < 1e-3, (int(d.max()), float((d > 1).mean()))
+    e = _engine(tmp_path)
+    got, _ = e.synthesize(LONG)                                  # a5: every chunk in one ragged GPU batch
+    assert len(e._last_plan) > 1
+    close(got, want)
+    e.cleanup()
+    e = _engine(tmp_path)
+    blocks = list(e.synthesize_stream(LONG, chunks_per_step=1))  # N4: streamed, one chunk per wave
+    assert len(blocks) > 1
+    close(np.concatenate(blocks), want)
+    e.cleanup()
+    # N2
+    text, serial = "Xin chào các bạn, hôm nay thế nào? Tôi rất vui được gặp bạn.", 3
+    e = _engine(tmp_path)
+    fe = BatchingFrontend(e, max_wait_ms=200.0, max_requests=4)
+    try:
+        futs = [fe.submit(text, speed=1.0, serial=serial), fe.submit("Tạm biệt và hẹn gặp lại.", speed=1.3, serial=4, gender="male")]
+        out = futs[0].result(timeout=300)[0]
+        futs[1].result(timeout=300)
+    finally:
+        fe.close()
+        e.cleanup()
+    orc = holder["oracle"]
+    ref_clip, ref_txt = ora.model_session_manager.select_sample()
+    inputs = ora._prepare_inputs(ref_clip, ref_txt, text, speed=1.0)
+    gen = torch.Generator().manual_seed(cfg.random_seed * 1000003 + serial)          # batching.py: the request's own noise stream
+    waves = []
+    for audio, ids, max_dur, _ts in inputs:
+        n = int(max_dur[0])
+        noise = torch.randn((n, orc.spec.n_mel), generator=gen, dtype=torch.float32)
+        _x, pcm = orc.synthesize(torch.from_numpy(np.asarray(audio).reshape(-1)), torch.from_numpy(np.asarray(ids).reshape(-1)), n, noise)
+        waves.append(pcm.numpy().astype(np.int16).reshape(-1))
+    joined = ora.audio_processor.concatenate_with_crossfade_improved(waves, cfg.cross_fade_duration, cfg.sample_rate)
+    ora.cleanup()
+    close(out, np.asarray(joined).reshape(-1))
+
+
 def test_voice_bank_cache_and_parity(tmp_path):
     """N3: clips are ingested once (GPU resample + normalise), served from HBM afterwards, equal to the host loader within
     1 LSB, and the engine output through the bank equals the output with host-loaded clips."""
