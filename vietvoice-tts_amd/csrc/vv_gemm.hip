@@ -671,9 +671,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float xv = acc[mh][nh][mi][ni][j];
-                                acc[mh][nh][mi][ni][j] = xv * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xv * (k1 + k3 * xv * xv)));
+                            for (int j = 0; j < 4; j += 2) {
+                                // two elements per instruction for the polynomial, the +1 and the final product (v_pk_mul_f32 /
+                                // v_pk_fma_f32 / v_pk_add_f32: both groups run their epilogues in the same interval, no MFMA stream
+                                // is issuing beside them); FF1 382 -> 368 us, profiles/r02/gemm_ab_pkact*.txt
+                                typedef __attribute__((ext_vector_type(2))) float f32x2;
+                                const f32x2 xv = {acc[mh][nh][mi][ni][j], acc[mh][nh][mi][ni][j + 1]};
+                                const f32x2 t = xv * (xv * xv * k3 + k1);
+                                const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                                const f32x2 o = xv * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                                acc[mh][nh][mi][ni][j] = o.x; acc[mh][nh][mi][ni][j + 1] = o.y;
                             }
         }
         if constexpr (MODE == MODE_GATE_STORE) {
