@@ -17,7 +17,8 @@
 // (column = time, 8 consecutive channels = one octet) is then ONE 16-byte LDS read, and the 32 lanes of a k-half read 32
 // CONSECUTIVE 16-byte slots: ds_read_b128 serves fixed 16-lane groups, each of which then covers all 64 banks (an interleaved
 // [time][16 ch] image, lanes 32 bytes apart, is 2-way conflicted: measured 4 % slower over the decode shapes) -- and the weight slab of a
-// group of TG taps as ws[tap][piece][octet][row][8 ch] (A fragments likewise).  Epilogue as K11.
+// group of TG taps as ws[tap][piece][octet][row][8 ch] (A fragments likewise).  The epilogue (bias, residual, MRF scale / accumulate)
+// is branch-free and batched: buffer loads / stores whose out-of-range elements carry an offset past num_records.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,8 +34,6 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;      // a native vector (HIP's uint4 is a struct of unions: register arrays of it end up in scratch)
 
 constexpr int XT = 256;       // time steps per workgroup
-
-__device__ __forceinline__ float lrelu_x(float x, float slope) { return x >= 0.f ? x : x * slope; }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 // Pair form of lrelu + split3 for the staging loop (v_pk_mul_f32 / v_pk_add_f32: one instruction per two elements; the max as
@@ -63,9 +62,6 @@ __device__ __forceinline__ void split3(float a, unsigned& h, unsigned& m, unsign
     m = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(m);
     l = __float_as_uint(r2);
-}
-__device__ __forceinline__ unsigned pack_hi(unsigned lo_elem, unsigned hi_elem) {      // (bf16 of lo_elem) | (bf16 of hi_elem) << 16
-    return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
 }
 
 // ---- weight split: Wt fp32 [Cin_pad][KW][rows_pad]  ->  Wb [chunks][KW][3][rows_pad][16]
