@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """GEMM A/B at the DiT block shapes (M = 102,400): every library on the command line is loaded into ONE process, timed in
-interleaved rounds and checked against the first library's output.   python tools/gemm_ab.py [rounds] lib1.so lib2.so ..."""
+interleaved rounds and checked against the first library's output.   python tools/gemm_ab.py [rounds] lib1.so lib2.so ...
+POSITION BIAS: the library timed first in a round runs 1-2.5 % slower than the ones after it (identical code measured 184.9 vs 180.2 us,
+profiles/r02/gemm_ab_ngroup_first.txt).  For differences of that size give every library in both positions (A B A B) and compare
+like with like, or confirm with alternated bench.py runs."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
