@@ -736,6 +736,12 @@ def test_groupnorm(hip_tiny, B, Cc, T, G):
         torch.cuda.synchronize()
         ref = fn(F.group_norm(x, G, gamma, beta, eps=1e-5))
         assert gu.rel_err(y, ref) < 1e-5
+    # data with a mean far from zero (the shifted one-pass variance must not cancel) against a float64 reference
+    xb = (x * 0.01 + 300.0).contiguous()
+    gu.check(eng, eng.lib.vv_groupnorm(eng.ctx, xb.to(gu.DEV).data_ptr(), y.data_ptr(), dg.data_ptr(), db.data_ptr(), B, Cc, T, G, 1e-5, 0, gu.stream()))
+    torch.cuda.synchronize()
+    ref64 = F.group_norm(xb.double(), G, gamma.double(), beta.double(), eps=1e-5)
+    assert gu.rel_err(y, ref64) < 2e-3          # the INPUT's fp32 rounding at 300 +- 0.03 already costs ~1e-3 of the normalised value
 
 
 # ------------------------------------------------------------------ N3: reference-clip ingest on the device

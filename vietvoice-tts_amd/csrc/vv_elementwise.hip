@@ -318,38 +318,57 @@ __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__
     }
 }
 
-// ---------------------------------------------------------------- K5: GroupNorm, channel-major [B][C][T]
-// One workgroup per (batch item, group): the group's C/G x T slab is contiguous.  Two streaming passes
-// (sum / sum of squared deviations -> numerically the two-pass form), wave-shuffle + LDS reductions, then
-// normalise with per-channel affine and an optional fused activation.  HBM-bound: 3 reads + 1 write per element
-// (the slab of a vocoder-sized group does not fit registers; L2 absorbs part of the re-reads).
+// ---------------------------------------------------------------- K5: GroupNorm over channel-major slabs [B][C][T]
+// One workgroup per (group, batch item) slab of (C / G) x T contiguous floats.  Two passes, 2 reads + 1 write per element:
+// (1) sum and sum of squares of (x - p), p = the slab's first element (a shifted one-pass variance: no cancellation for data with
+// a large mean), 16-byte loads, wave-shuffle + LDS reductions; (2) normalise with the per-channel affine and the optional fused
+// activation, 16-byte loads and stores.  A slab that is not 16-byte aligned or whose T is not a multiple of 4 takes scalar accesses.
 __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int C, int T, int G, float eps, int act) {
-    __shared__ float red[4];
-    __shared__ float stat[2];
+    __shared__ float red[2][4];
     const int b = blockIdx.y, g = blockIdx.x;
     const int cpg = C / G;
     const size_t n = (size_t)cpg * T;
     const float* xs = x + ((size_t)b * C + (size_t)g * cpg) * T;
     float* ys = y + ((size_t)b * C + (size_t)g * cpg) * T;
-    auto block_sum = [&](float v) {
-        v = wave_sum(v);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        return (red[0] + red[1]) + (red[2] + red[3]);
-    };
-    float s = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 256) s += xs[i];
-    const float mean = block_sum(s) / (float)n;
-    float q = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 256) { const float d = xs[i] - mean; q += d * d; }
-    const float rstd = rsqrtf(block_sum(q) / (float)n + eps);
-    for (size_t i = threadIdx.x; i < n; i += 256) {
-        const int c = g * cpg + (int)(i / T);
-        const float v = (xs[i] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
-        ys[i] = act_apply(v, act);
+    const bool vec = (T & 3) == 0 && (((uintptr_t)xs | (uintptr_t)ys) & 15) == 0;
+    const float p = xs[0];
+    float s = 0.f, q = 0.f;
+    if (vec) {
+        const size_t n4 = n >> 2;
+        for (size_t i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = *(const float4*)(xs + i * 4);
+            const float a0 = v.x - p, a1 = v.y - p, a2 = v.z - p, a3 = v.w - p;
+            s += (a0 + a1) + (a2 + a3);
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    } else {
+        for (size_t i = threadIdx.x; i < n; i += 256) { const float d = xs[i] - p; s += d; q += d * d; }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    const float sd = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)n;      // mean of x - p
+    const float var = fmaxf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)n - sd * sd, 0.f);
+    const float mean = p + sd, rstd = rsqrtf(var + eps);
+    if (vec) {
+        const int t4 = T >> 2;
+        const size_t n4 = n >> 2;
+        for (size_t i = threadIdx.x; i < n4; i += 256) {
+            const int c = g * cpg + (int)(i / t4);
+            const float ga = (gamma ? gamma[c] : 1.f) * rstd, be = beta ? beta[c] : 0.f;
+            const float4 v = *(const float4*)(xs + i * 4);
+            float4 o;
+            o.x = act_apply((v.x - mean) * ga + be, act); o.y = act_apply((v.y - mean) * ga + be, act);
+            o.z = act_apply((v.z - mean) * ga + be, act); o.w = act_apply((v.w - mean) * ga + be, act);
+            *(float4*)(ys + i * 4) = o;
+        }
+    } else {
+        for (size_t i = threadIdx.x; i < n; i += 256) {
+            const int c = g * cpg + (int)(i / T);
+            ys[i] = act_apply((xs[i] - mean) * ((gamma ? gamma[c] : 1.f) * rstd) + (beta ? beta[c] : 0.f), act);
+        }
     }
 }
 
