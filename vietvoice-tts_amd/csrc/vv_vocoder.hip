@@ -356,26 +356,44 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
             }
         }
     }
+    // epilogue as in conv_mfma_kernel: branch-free, batched buffer loads / stores (an element outside the rows or the window's
+    // central columns carries an offset past num_records); same arithmetic, same order: still bit-identical to the two launches
+    const size_t slab = (size_t)C * T;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)b * slab), 0, (int)min(slab * 4, (size_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (int)min(slab * 4, (size_t)0x7fffffff), 0x00020000);
 #pragma unroll
     for (int ti = 0; ti < CT; ++ti) {
         const int cc = (wave * CT + ti) * 32 + r32;  // conv2 output column
         const int t = w0 + half + cc;
-        if (cc >= P - half && cc < P - half + VT2 && t < T) {
-            float* outb = out + (size_t)b * C * T;
+        const bool col_ok = cc >= P - half && cc < P - half + VT2 && t < T;
 #pragma unroll
-            for (int ri = 0; ri < RT; ++ri)
+        for (int ri = 0; ri < RT; ++ri)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+            for (int rh = 0; rh < 16; rh += 8) {
+                unsigned off[8];
+                float bv[8], yv[8], ov[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = rh + k;
                     const int row = ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row >= C) continue;
-                    const size_t o = (size_t)row * T + t;
-                    float v = acc[ri][ti][r] + b2[row];
-                    v += yb[o];
-                    v *= out_scale;
-                    if (accumulate) v += outb[o];
-                    outb[o] = v;
+                    off[k] = (col_ok && row < C) ? (unsigned)(row * T + t) * 4u : 0x80000000u;
+                    bv[k] = b2[min(row, C - 1)];
                 }
-        }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) yv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_y, (int)off[k], 0, 0));
+                if (accumulate) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ov[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, (int)off[k], 0, 0));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = acc[ri][ti][rh + k] + bv[k];
+                    v += yv[k];
+                    v *= out_scale;
+                    if (accumulate) v += ov[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, (int)off[k], 0, 0);
+                }
+            }
     }
 }
 
@@ -553,6 +571,7 @@ int vvk_mrf_pair(const vv_mrf_args* a, hipStream_t st, const char** err) {
     if (a->dil < 1 || a->dil > 5) { *err = "mrf_resblock: dilation 1..5"; return -22; }
     if (!(a->slope > 0.f && a->slope <= 1.f)) { *err = "mrf_resblock: slope must be in (0, 1]"; return -22; }
     if (a->out == a->y) { *err = "mrf_resblock: out must not alias y (neighbouring workgroups read y's halo)"; return -22; }
+    if ((size_t)a->C * a->T * 4 >= ((size_t)1 << 31)) { *err = "mrf_resblock: a [C][T] slab of one item reaches 2 GiB"; return -22; }
     const bool wide = a->C == 64;
     switch (a->KW) {
         // 128-column windows for both widths: a 256-column window for C = 32 (half the halo recompute) measured SLOWER at the
