@@ -8,9 +8,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export CONV_SHAPES=${CONV_SHAPES:-"res1 C128 k3 d1,res1 C128 k11 d1,res3 C32 k3 d1"}
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_WAVES FETCH_SIZE WRITE_SIZE"; do
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS"; do       # (a fifth group mixing GRBM / TCC counters hung: HBM traffic is tools/profile_conv_traffic.sh)
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/cpmc_$i -- python3 $ROOT/tools/conv_bench.py 1 > $OUT/cpmc_$i.log 2>&1 || { echo "group $i failed"; tail -3 $OUT/cpmc_$i.log; }
+  echo "pass $i: $grp" >> $OUT/cpmc_progress.txt
+  timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d $OUT/cpmc_$i -- python3 $ROOT/tools/conv_bench.py 1 > $OUT/cpmc_$i.log 2>&1 || { echo "group $i failed"; tail -3 $OUT/cpmc_$i.log; }
 done
 python3 - <<PY
 import csv, glob, collections
