@@ -68,6 +68,9 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 }
 
 // ------------------------------------------------------------------------------------ bf16
+#if (defined(VV_ATTN_V2) || defined(VV_ATTN_TAILSKIP)) && !defined(VV_ATTN_STAGE_EARLY)
+#error "the V2 / TAILSKIP A/B paths leave the tile before the late staging point: build them with -DVV_ATTN_STAGE_EARLY"
+#endif
 #ifdef VV_ATTN_LB4
 #define VV_ATTN_MIN_WAVES 4
 #else
@@ -160,7 +163,12 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
     for (int kt = 0; kt < n_tiles; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // The next tile's K/V pieces (4 LDS-DMA instructions per wave, 60-185 cycles of issue each) are issued BETWEEN the
+        // exponentials and the PV block of this tile, not here in front of the QK^T block: 705 -> 683 us at the bench shape,
+        // bit-identical (profiles/r02/attn_ab_stage.txt; -DVV_ATTN_STAGE_EARLY builds the old placement).
+#ifdef VV_ATTN_STAGE_EARLY
         if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+#endif
 #ifdef VV_ATTN_TAILSKIP
         if (q0 >= q_lim) continue;           // a wave whose 32 queries all lie past the sequence only stages its K/V pieces
 #endif
@@ -322,8 +330,14 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
         if (!redo) {
             scores();
             psum = exps();
+#ifndef VV_ATTN_STAGE_EARLY
+            if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+#endif
             redo = __any(!(psum <= RESCALE_SUM));
         }
+#ifndef VV_ATTN_STAGE_EARLY
+        else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
+#endif
         if (redo) {
             scores();
             float mx = s[0][0];
