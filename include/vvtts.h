@@ -21,6 +21,13 @@
 extern "C" {
 #endif
 
+/* exported entry points: the library is built with -fvisibility=hidden, only these symbols leave it */
+#if defined(__GNUC__)
+#define VV_API __attribute__((visibility("default")))
+#else
+#define VV_API
+#endif
+
 #define VV_DTYPE_F32 0
 #define VV_DTYPE_BF16 1
 #define VV_MAX_UP 8
@@ -57,19 +64,19 @@ typedef struct vv_model_cfg {
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* replaces onnxruntime.InferenceSession creation, core/model.py:96-102 */
-int vv_create(vv_ctx** out, int device, const vv_model_cfg* cfg, int acoustic_dtype);
-void vv_destroy(vv_ctx* ctx);
-const char* vv_last_error(const vv_ctx* ctx);   /* ctx may be NULL: last create error */
-const char* vv_version(void);
+VV_API int vv_create(vv_ctx** out, int device, const vv_model_cfg* cfg, int acoustic_dtype);
+VV_API void vv_destroy(vv_ctx* ctx);
+VV_API const char* vv_last_error(const vv_ctx* ctx);   /* ctx may be NULL: last create error */
+VV_API const char* vv_version(void);
 
 /* Bind one named tensor of the (already uploaded) flat weight buffer.  Layouts: DESIGN.md 3. */
-int vv_bind_weight(vv_ctx* ctx, const char* name, const void* device_ptr, uint64_t bytes);
+VV_API int vv_bind_weight(vv_ctx* ctx, const char* name, const void* device_ptr, uint64_t bytes);
 /* Verify every tensor the three stages need is bound (names listed in the error if not). */
-int vv_finalize_weights(vv_ctx* ctx);
+VV_API int vv_finalize_weights(vv_ctx* ctx);
 
 /* ODE time grid: sinus[n_steps][time_freq_dim] (host), dt[n_steps] (host).  Runs the time MLP and
  * every block's AdaLN projection once on the GPU and keeps the modulation tables in HBM. */
-int vv_set_time_grid(vv_ctx* ctx, const float* sinus_host, const float* dt_host, int n_steps, void* stream);
+VV_API int vv_set_time_grid(vv_ctx* ctx, const float* sinus_host, const float* dt_host, int n_steps, void* stream);
 
 /* ---- the three stages (device-resident, batched) ------------------------------------------ */
 /* replaces sessions['preprocess'].run, core/tts_engine.py:133-146.
@@ -77,7 +84,7 @@ int vv_set_time_grid(vv_ctx* ctx, const float* sinus_host, const float* dt_host,
  * (= max_duration per item, frames), N = padded frame count (>= every seq_len).
  * Outputs: cat_mel_text, cat_mel_text_drop [B][N][n_mel+text_dim] f32, ref_signal_len[B] int32.
  * (noise is supplied by the caller; the rope tables are slices of the bound constant tables.) */
-int vv_preprocess(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len,
+VV_API int vv_preprocess(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len,
                   const int32_t* audio_len, const int32_t* text_ids, int ld_text, const int32_t* text_len,
                   const int32_t* seq_len, float* cat_mel_text, float* cat_mel_text_drop,
                   int32_t* ref_signal_len, void* stream);
@@ -85,21 +92,21 @@ int vv_preprocess(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld_audio,
 /* replaces the loop over sessions['transformer'].run, core/tts_engine.py:148-174: n_steps Euler
  * steps of the flow ODE starting at step index step0, state x [B][N][n_mel] f32 updated in HBM.
  * rope tables are [>=N][head_dim] f32 (q tables carry the softmax scale). */
-int vv_transformer_steps(vv_ctx* ctx, int B, int N, const int32_t* seq_len, float* x, const float* cat_mel_text,
+VV_API int vv_transformer_steps(vv_ctx* ctx, int B, int N, const int32_t* seq_len, float* x, const float* cat_mel_text,
                          const float* cat_mel_text_drop, const float* rope_cos_q, const float* rope_sin_q,
                          const float* rope_cos_k, const float* rope_sin_k, int step0, int n_steps, void* stream);
 
 /* The same call with the per-item lengths also handed over on the HOST (same values as the device array): the host needs them
  * for the launch shapes, so vv_transformer_steps reads them back (one 4*B-byte copy + stream synchronisation per call); this form
  * has no synchronisation at all and can be captured into a hipGraph once the context arena is large enough. */
-int vv_transformer_steps_h(vv_ctx* ctx, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x,
+VV_API int vv_transformer_steps_h(vv_ctx* ctx, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x,
                            const float* cat_mel_text, const float* cat_mel_text_drop, const float* rope_cos_q, const float* rope_sin_q,
                            const float* rope_cos_k, const float* rope_sin_k, int step0, int n_steps, void* stream);
 
 /* replaces sessions['decode'].run, core/tts_engine.py:176-187: frames [ref_len, seq_len) of x ->
  * vocoder -> int16 PCM.  pcm [B][ld_pcm], ld_pcm >= t_gen_max*hop; pcm_len[B] = samples per item.
  * wave_f32 (optional, [B][t_gen_max*hop]) receives the pre-quantisation waveform. */
-int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
+VV_API int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
               int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream);
 
 /* The same decode stage with every intermediate carved from a CALLER-OWNED device block `ws` (256-byte aligned,
@@ -107,11 +114,11 @@ int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_sign
  * that needs more bytes (vv_ws_generation counts those moves); a launch sequence captured into a hipGraph
  * (BASELINE.json configs[4], "hipGraph-captured vocoder step") must therefore run through vv_decode_into so that
  * nothing it points at can move while the graph lives.  No reference counterpart (the reference never captures). */
-int vv_decode_ws_bytes(vv_ctx* ctx, int B, int t_gen_max, uint64_t* bytes);
-int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
+VV_API int vv_decode_ws_bytes(vv_ctx* ctx, int B, int t_gen_max, uint64_t* bytes);
+VV_API int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
                    int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* ws, uint64_t ws_bytes,
                    void* stream);
-uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
+VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
 
 /* Context switches (explicit API, never the environment).  "fuse_mrf": run the MRF resblock pairs of the C <= 64 vocoder
  * stages through vv_mrf_resblock's fused kernel -- 0 never (two vv_conv1d launches per pair), 1 always, 2 (default) for
@@ -121,7 +128,7 @@ uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context a
  * consuming norms extra reads).  Rows in the tail sum bf16-rounded K parts in fp32 (same tolerance class as the plain launch,
  * not bit-identical to it); the fp32 path never splits.
  * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
-int vv_set_option(vv_ctx* ctx, const char* name, int value);
+VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
 #define VV_PROF_GEMM 0
@@ -134,9 +141,9 @@ int vv_set_option(vv_ctx* ctx, const char* name, int value);
 #define VV_PROF_MEL 7
 #define VV_PROF_TEXT 8
 #define VV_PROF_NCLASS 9
-int vv_prof_enable(vv_ctx* ctx, int on);
+VV_API int vv_prof_enable(vv_ctx* ctx, int on);
 /* Synchronises, then fills per class: launches, total ms, algorithmic flops, algorithmic bytes. */
-int vv_prof_collect(vv_ctx* ctx, int64_t* launches, double* ms, double* flops, double* bytes);
+VV_API int vv_prof_collect(vv_ctx* ctx, int64_t* launches, double* ms, double* flops, double* bytes);
 
 /* ---- single-kernel entry points (unit parity tests call these through the ABI) ------------- */
 typedef struct vv_gemm_args {
@@ -156,11 +163,11 @@ typedef struct vv_gemm_args {
     void* C_tail;              /* tail_parts > 1: [tail_parts - 1][M - tail_row0][ldc] partial products of rows >= tail_row0; C holds
                                   part 0 (with the bias), the consumer adds the rest (vv_ln_args.delta_tail) */
 } vv_gemm_args;
-int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
+VV_API int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 /* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the
  * gate-store form can split the K range of the last row panels `parts` ways so that the remainder costs 1/parts of a round.
  * Returns the plan for this shape on the current device: rows >= row0 are split `parts` ways (parts = 0: nothing to gain). */
-int vv_gemm_tail_plan(vv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts);
+VV_API int vv_gemm_tail_plan(vv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts);
 
 typedef struct vv_attn_args {
     int32_t dtype;
@@ -173,7 +180,7 @@ typedef struct vv_attn_args {
     int32_t total_rows;        /* rows in the qkv / out buffers (bounds the K/V buffer resource; reads past it return zero).
                                   Required (> 0) with row_start; 0 = n_seq * seq_n in the padded layout */
 } vv_attn_args;
-int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
+VV_API int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
 
 typedef struct vv_ln_args {
     int32_t out_dtype;
@@ -191,7 +198,7 @@ typedef struct vv_ln_args {
     int32_t delta_tail_parts, delta2_tail_parts;   /*   delta_tail [parts - 1][R - tail_row0][ld_delta] (0 / 1 parts = none)  */
     const void *delta_tail, *delta2_tail;          /*   in part order, right after the delta they belong to                   */
 } vv_ln_args;
-int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
+VV_API int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
 
 typedef struct vv_posconv_args {
     int32_t dtype, out_dtype;
@@ -204,7 +211,7 @@ typedef struct vv_posconv_args {
     const int32_t* seq_len;
     const int32_t* row_start;  /* optional [n_seq]: packed ragged rows, as in vv_attn_args */
 } vv_posconv_args;
-int vv_posconv(vv_ctx* ctx, const vv_posconv_args* args, void* stream);
+VV_API int vv_posconv(vv_ctx* ctx, const vv_posconv_args* args, void* stream);
 
 typedef struct vv_conv_args {
     const float* in;          /* [B][Cin][T_in]  */
@@ -220,11 +227,11 @@ typedef struct vv_conv_args {
                                  matrix time) instead of v_mfma_f32_32x32x2_f32.  Same result class, not bit-identical. */
     int32_t wg_rows;          /* x3 only: 0 = default (64-row workgroups of 4 waves), 128 = 128-row workgroups of 8 waves when rows_total > 64 */
 } vv_conv_args;
-int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
+VV_API int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
 /* W fp32 [Cin_pad][KW][rows_pad] -> out [ceil(Cin_pad / 16)][KW][3 pieces][2 octets][rows_pad][8] bf16 (w = h + m + l exactly, each piece the
  * truncated leading 8 significand bits of the remainder).  vv_conv_split_bytes gives the size of `out` (16-byte aligned). */
-uint64_t vv_conv_split_bytes(int32_t Cin_pad, int32_t KW, int32_t rows_pad);
-int vv_conv_split_weights(vv_ctx* ctx, const float* W, int32_t Cin_pad, int32_t KW, int32_t rows_pad, void* out, void* stream);
+VV_API uint64_t vv_conv_split_bytes(int32_t Cin_pad, int32_t KW, int32_t rows_pad);
+VV_API int vv_conv_split_weights(vv_ctx* ctx, const float* W, int32_t Cin_pad, int32_t KW, int32_t rows_pad, void* out, void* stream);
 
 /* K12, one (kernel, dilation) pair of an MRF resblock fused through LDS (SURVEY 8(a) K12 / 8(b) vv_mrf_resblock):
  *   out = [accumulate ? out : 0] + out_scale * ( conv2(lrelu(conv1(lrelu(y)))) + y ),  conv1 dilated, conv2 undilated, C -> C.
@@ -239,31 +246,31 @@ typedef struct vv_mrf_args {
     float slope, out_scale;
     const int32_t* len_in;    /* optional per-item valid length */
 } vv_mrf_args;
-int vv_mrf_resblock(vv_ctx* ctx, const vv_mrf_args* args, void* stream);
+VV_API int vv_mrf_resblock(vv_ctx* ctx, const vv_mrf_args* args, void* stream);
 
-int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32,
+VV_API int vv_conv_post(vv_ctx* ctx, const float* in, const float* w, float bias, int16_t* pcm, int ld_pcm, float* wave_f32,
                  int B, int C, int T, int KW, float pre_slope, const int32_t* len_in, void* stream);
-int vv_mel(vv_ctx* ctx, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max,
+VV_API int vv_mel(vv_ctx* ctx, const int16_t* audio, int ld_audio, const int32_t* audio_len, float* mel, int B, int F_max,
            void* stream);
 /* K5 GroupNorm over channel-major [B][C][T] fp32 (G groups), optional per-channel affine and fused activation code */
-int vv_groupnorm(vv_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G,
+VV_API int vv_groupnorm(vv_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int B, int C, int T, int G,
                  float eps, int act, void* stream);
 /* out[pos][2i] = cos[pos][2i], out[pos][2i+1] = sin[pos][2i]  (tables with duplicated pairs, n rows x 64) */
-int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
+VV_API int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, float* out, int n, void* stream);
 /* out[r][0..63] = compact[pos[r]][0..63]: the compact table gathered once per call for every packed row */
-int vv_rope_rows(vv_ctx* ctx, const float* compact, const int32_t* pos, float* out, int rows, void* stream);
-int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
+VV_API int vv_rope_rows(vv_ctx* ctx, const float* compact, const int32_t* pos, float* out, int rows, void* stream);
+VV_API int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
 
 /* ---- reference-clip ingest on the device.  Together they replace the arithmetic of
  * AudioProcessor.load_audio after decoding (reference core/audio_processor.py:16-44: set_frame_rate, then
  * normalize_to_int16 = remove DC, peak -> 29491, truncate). */
 /* polyphase FIR resampler: y[n] = sum_i x[i] * taps[(n + skip) * down - i * up], f64 accumulate, f32 out.
  * taps = host-designed low-pass already scaled by `up` (f64, device). */
-int vv_resample_poly(vv_ctx* ctx, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip,
+VV_API int vv_resample_poly(vv_ctx* ctx, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip,
                      float* y, int n_out, void* stream);
 /* n_clips mono f32 clips stored back to back, clip i = [offsets[i], offsets[i+1]); out has the same offsets.
  * stats = 2 * n_clips doubles of device scratch. */
-int vv_normalize_clips(vv_ctx* ctx, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats,
+VV_API int vv_normalize_clips(vv_ctx* ctx, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats,
                        int16_t* out, void* stream);
 
 #ifdef __cplusplus

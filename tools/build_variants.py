@@ -17,5 +17,5 @@ for item in sys.argv[2:]:
     subprocess.run(cmd, check=True)
     objs = [obj if s == stem else os.path.join(be.OBJ, s + ".o") for s in be.SOURCES]
     lib = os.path.join(out_dir, f"libvvtts_{name}.so")
-    subprocess.run([be._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    subprocess.run([be._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + be.LINK_FLAGS + ["-o", lib] + objs, check=True)
     print(lib)

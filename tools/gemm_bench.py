@@ -1,10 +1,7 @@
 #!/usr/bin/env python3
 """GEMM microbenchmark through the C ABI (the DiT block shapes at B=32): TFLOP/s per epilogue mode.
 
-Timing-only ablations (VV_GEMM_DBG bits) exist only in the A/B library:
-    python vietvoice-tts_amd/build_ext.py --ablate
-    VVTTS_LIB=vietvoice-tts_amd/libvvtts_hip_ablate.so VV_GEMM_DBG=<bits> python tools/gemm_bench.py
-The shipped libvvtts_hip.so ignores VV_GEMM_DBG (the branches are compiled out)."""
+A/B builds of one kernel file: tools/build_variants.py + tools/gemm_ab.py (VVTTS_LIB selects a library here)."""
 import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -14,8 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvvtts_hip.so")
 SOURCES = ["vv_gemm", "vv_attention", "vv_elementwise", "vv_posconv", "vv_vocoder", "vv_vocoder_x3", "vv_mel", "vv_ingest", "vv_api"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 EXTRA_FLAGS = {}      # per-file extras (none needed at present)
+LINK_FLAGS = ["-Wl,--version-script=" + os.path.join(CSRC, "vvtts.map")]      # exports = the vv_* entry points of include/vvtts.h
 
 
 def _hipcc() -> str:
@@ -32,20 +33,7 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
-    """ablate=True builds libvvtts_hip_ablate.so with -DVV_GEMM_ABLATE (the timing-only GEMM ablation bits read from
-    VV_GEMM_DBG): an A/B library for tools/gemm_bench.py, selected with VVTTS_LIB.  The shipped library has no such path."""
-    global OBJ, LIB
-    if ablate:
-        obj_dir, lib = os.path.join(HERE, "build", "ablate"), os.path.join(HERE, "libvvtts_hip_ablate.so")
-        saved = (OBJ, LIB, list(FLAGS))
-        OBJ, LIB = obj_dir, lib
-        FLAGS.append("-DVV_GEMM_ABLATE")
-        try:
-            return _build(force, verbose)
-        finally:
-            OBJ, LIB = saved[0], saved[1]
-            FLAGS[:] = saved[2]
+def build(force: bool = False, verbose: bool = False) -> str:
     return _build(force, verbose)
 
 
@@ -71,7 +59,7 @@ def _build(force: bool, verbose: bool) -> str:
         res = list(ex.map(one, SOURCES))
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + LINK_FLAGS + ["-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -79,4 +67,4 @@ def _build(force: bool, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -53,12 +53,8 @@ __device__ __forceinline__ float half_sum(float v) {
 struct AttnBlock { int qb, head, seq; bool valid; };
 __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
     const int b = blockIdx.x;
-#ifdef VV_ATTN_NO_XCD                                  // A/B build: the round-1 order (query blocks of a pair on consecutive ids = 8 XCDs)
-    const int pair = b / nqb, j = b;
-#else
     const int xcd = b & 7, j = b >> 3;
     const int pair = (j / nqb) * 8 + xcd;              // (sequence, head) pairs are dealt to the XCD groups round-robin
-#endif
     AttnBlock r;
     r.qb = j % nqb;
     r.valid = pair < heads * n_seq;
@@ -68,15 +64,7 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 }
 
 // ------------------------------------------------------------------------------------ bf16
-#if (defined(VV_ATTN_V2) || defined(VV_ATTN_TAILSKIP)) && !defined(VV_ATTN_STAGE_EARLY)
-#error "the V2 / TAILSKIP A/B paths leave the tile before the late staging point: build them with -DVV_ATTN_STAGE_EARLY"
-#endif
-#ifdef VV_ATTN_LB4
-#define VV_ATTN_MIN_WAVES 4
-#else
-#define VV_ATTN_MIN_WAVES 2
-#endif
-__global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
                                                            const int* __restrict__ row_start, int total_rows, int heads, int n_seq) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
@@ -165,13 +153,7 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
         __syncthreads();
         // The next tile's K/V pieces (4 LDS-DMA instructions per wave, 60-185 cycles of issue each) are issued BETWEEN the
         // exponentials and the PV block of this tile, not here in front of the QK^T block: 705 -> 683 us at the bench shape,
-        // bit-identical (profiles/r02/attn_ab_stage.txt; -DVV_ATTN_STAGE_EARLY builds the old placement).
-#ifdef VV_ATTN_STAGE_EARLY
-        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-#endif
-#ifdef VV_ATTN_TAILSKIP
-        if (q0 >= q_lim) continue;           // a wave whose 32 queries all lie past the sequence only stages its K/V pieces
-#endif
+        // bit-identical (profiles/r02/attn_ab_stage.txt).
         const char* sK = smem + (kt & 1) * 16384;
         const char* sV = sK + 8192;
 
@@ -183,11 +165,9 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
         const int kbase = kt * 64;
         // The two MFMA blocks of a tile issue at raised wave priority (s_setprio 1): among the four waves of a SIMD (four different
         // workgroups) the one that is ready to feed the matrix pipe goes first, the ones in their softmax blocks fill in behind it.
-        // 703 -> 694 us at the bench shape, bit-identical (profiles/r02/attn_ab_prio*.txt; -DVV_ATTN_NO_PRIO builds the old order).
+        // 703 -> 694 us at the bench shape, bit-identical (profiles/r02/attn_ab_prio*.txt).
         auto scores = [&]() {
-#ifndef VV_ATTN_NO_PRIO
             __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
@@ -197,9 +177,7 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
                 }
             }
-#ifndef VV_ATTN_NO_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             if (kbase + 64 > kv_len) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -230,114 +208,15 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
         // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
         // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
         // which path ran.
-#ifdef VV_ATTN_V2
-        // ---- interior tiles (not the first, not the masked last one): the 64 keys are two 32-key halves of the online softmax,
-        // software-pipelined INSIDE the wave: the exponentials of half 0 are issued between the QK^T MFMAs of half 1, the
-        // exponentials of half 1 between the PV MFMAs of half 0 (a wave issues in order: without the interleave its matrix pipe
-        // idles through every softmax block and its VALU through every MFMA block).  Same registers as the whole-tile form
-        // (s0/s1 are s[0]/s[1]); each half is its own speculative sub-tile: half 0 failing its check falls back to the whole-tile
-        // careful path below (nothing is committed yet), half 1 failing redoes half 1 alone against the state that already
-        // holds half 0.
-        bool fast_done = false;
-        if (kt != 0 && kbase + 64 <= kv_len) {
-            auto qk_half = [&](int kb, f32x16 c) {
-#pragma unroll
-                for (int ds = 0; ds < 4; ++ds) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], c, 0, 0, 0);
-                }
-                return c;
-            };
-            auto exp_half = [&](f32x16& v) -> float {
-                float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = fast_exp2(v[r]);
-                    ps[r & 3] += pv;
-                    v[r] = pv;
-                }
-                return (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            };
-            auto pv_half = [&](int kb, const f32x16& pr) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const f32x8 pv = {pr[8 * st + 0], pr[8 * st + 1], pr[8 * st + 2], pr[8 * st + 3],
-                                      pr[8 * st + 4], pr[8 * st + 5], pr[8 * st + 6], pr[8 * st + 7]};
-                    const bf16x8 pf = __builtin_convertvector(pv, bf16x8);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
-                        const char* a1 = a0 + 8 * 128;
-                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
-                        const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-                    }
-                }
-            };
-            const f32x16 sx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
-            s[0] = qk_half(0, sx);
-            s[1] = qk_half(1, sx);
-            const float p0 = exp_half(s[0]);
-            // program order of this region: ext + 4 MFMAs of half 0, then each MFMA of half 1 followed by 4 exp + 4 add of half 0
-            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-            if (!__any(!(p0 <= RESCALE_SUM))) {
-                l_run += p0;
-                pv_half(0, s[0]);
-                float p1 = exp_half(s[1]);
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);          // the 8 v_cvt_pk of half 0 first
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 4, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 1);
-                }
-                if (__any(!(p1 <= RESCALE_SUM))) {                           // rare: half 1 alone, the careful way
-                    s[1] = qk_half(1, __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0));   // sx is not kept live for this
-                    float mx = s[1][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-                    mx = half_max(mx);
-                    const float m_new = bf16_round(m_eff + fmaxf(mx, 0.f));
-                    const float d = m_new - m_eff;
-                    const float alpha = fast_exp2(-d);
-                    l_run *= alpha;                                          // l and O already hold half 0 at the old reference
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[1][r] -= d;
-                    m_eff = m_new;
-                    q_ext = make_q_ext(-m_new, h);
-                    p1 = exp_half(s[1]);
-                }
-                l_run += p1;
-                pv_half(1, s[1]);
-                fast_done = true;
-            }
-        }
-        if (fast_done) continue;
-#endif
         float psum = 0.f;
         bool redo = kt == 0;
         if (!redo) {
             scores();
             psum = exps();
-#ifndef VV_ATTN_STAGE_EARLY
             if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-#endif
             redo = __any(!(psum <= RESCALE_SUM));
         }
-#ifndef VV_ATTN_STAGE_EARLY
         else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
-#endif
         if (redo) {
             scores();
             float mx = s[0][0];
@@ -367,9 +246,7 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
         l_run += psum;
 
         // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
-#ifndef VV_ATTN_NO_PRIO
         __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -387,9 +264,7 @@ __global__ __launch_bounds__(256, VV_ATTN_MIN_WAVES) void attn_bf16_kernel(const
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
-#ifndef VV_ATTN_NO_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     }
     const float l_tot = half_sum(l_run);
     const float inv = 1.0f / l_tot;

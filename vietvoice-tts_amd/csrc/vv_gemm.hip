@@ -18,16 +18,9 @@
 // XCD's L2 while the (small) weight matrix stays hot in every L2 / MALL.
 #include "vv_common.h"
 #include "vv_kernels.h"
-// G1 (round 2): counted output stores + async bias / gate prefetch in the persistent kernel; measured -2.8 ... -4.3 % on the
-// out-proj / FF1 / FF2 shapes, bit-identical results (profiles/r02/gemm_notes.md).  -DVV_GEMM_NO_G1 builds the round-1 epilogue
-// for A/B runs (tools/build_variants.py, tools/gemm_ab.py).
-#if !defined(VV_GEMM_NO_G1) && !defined(VV_GEMM_ABLATE)
-#define VV_GEMM_G1 1
-#endif
-// E2 (round 2): both wave groups run their epilogue in the same barrier interval; -3.2 % on the four block shapes, bit-identical.
-#if !defined(VV_GEMM_NO_E2) && !defined(VV_GEMM_ABLATE)
-#define VV_GEMM_E2 1
-#endif
+// Round-2 structure of the persistent kernel, all measured in profiles/r02/gemm_notes.md (the rejected variants live in the
+// notes and in git history, not here): G1 = counted output stores + async bias / gate prefetch; E2 = both wave groups run their
+// epilogue in the same barrier interval; A1 = scalar tile origin for the activation LDS-DMA.
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -60,17 +53,7 @@ struct EpiArgs {
     unsigned seq_rcp;        // ceil(2^32 / seq_n): row -> position without a table when every sequence has seq_n rows (m * seq_n < 2^32)
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
-#ifdef VV_GEMM_ABLATE
-    int dbg;     // timing-only ablations, A/B build for tools/gemm_bench.py ONLY (libvvtts_hip_ablate.so, selected with VVTTS_LIB):
-                 // bit0 = no wait/barrier, bit1 = no loads in the loop, 4/8 = kernel choice, 128/512/1024 = epilogue variants
-#endif
 };
-// The shipped library has no ablation path: VV_DBG folds to the constant 0 and every branch on it is compiled out.
-#ifdef VV_GEMM_ABLATE
-#define VV_DBG(e) ((e).dbg)
-#else
-#define VV_DBG(e) 0
-#endif
 
 // fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
 __device__ __forceinline__ float fast_sigmoid(float x) {
@@ -180,11 +163,9 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
         for (int kt = 0; kt < nk; ++kt) {
-            if (!(VV_DBG(e) & 1)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            if (kt + 1 < nk && !(VV_DBG(e) & 2)) stage(kt + 1, (kt + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
             const char* sa = smem + (kt & 1) * STAGE_BYTES;
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -363,7 +344,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // unit types 0 Wn0, 1 Am0, 2 Wn1, 3 Am1; this wave fills pieces 2*wave, 2*wave+1 of every unit.
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
-#ifdef VV_GEMM_G1
     // G1: (1) every tile issues exactly 16 output stores per wave -- buffer stores whose out-of-range lanes carry an offset past
     // num_records (dropped by the hardware) instead of an exec-masked global store that the compiler may branch around -- so the
     // first K-tile of EVERY tile may leave the previous tile's stores in flight (vmcnt(24)); 16 dropped stores in the prologue
@@ -384,15 +364,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
         return v;
     };
-#else
-    constexpr bool G1 = false;
-#endif
     unsigned voff_w[2][2];     // [n-half][piece]  relative to the tile's first weight row
     int loc_a[2];              // [piece]          token row of the piece inside the tile (m-half 0); + 64 for m-half 1
     unsigned cbyte[2];
-#ifndef VV_GEMM_NO_A1
     unsigned voff_a[2][2];     // [m-half][piece]  per-lane byte offset of the piece's token row inside the tile (A1, below)
-#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int ur = (wave * 2 + u) * 8 + (lane >> 3);              // row inside the unit
@@ -400,10 +375,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         loc_a[u] = (ur >> 6) * 128 + (ur & 63);
 #pragma unroll
         for (int h = 0; h < 2; ++h) voff_w[h][u] = (unsigned)((ur >> 5) * 64 + h * 32 + (ur & 31)) * (unsigned)ldw * 2u + cbyte[u];
-#ifndef VV_GEMM_NO_A1
 #pragma unroll
         for (int h = 0; h < 2; ++h) voff_a[h][u] = (unsigned)(loc_a[u] + h * 64) * (unsigned)lda * 2u + cbyte[u];
-#endif
     }
     // stage unit `type` of K-tile Tk (parity par) of the tile whose origin is (bmS, bnS)
     auto stage = [&](auto type_c, int bmS, int bnS, int Tk, int par) {
@@ -413,14 +386,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if constexpr (type & 1) {
-#ifndef VV_GEMM_NO_A1
                 // A1: one v_add per piece (tile origin is a scalar) instead of add + clamp + 64-bit multiply in every phase.  Rows past
                 // M need no clamp: their offset is past the resource's num_records (the origin is part of the VECTOR offset, the
                 // part the hardware range-checks), so the DMA writes zeros; those rows are computed but never stored.
                 const unsigned v = voff_a[h][u] + (unsigned)bmS * (unsigned)lda * 2u;
-#else
-                const unsigned v = (unsigned)min(bmS + loc_a[u] + h * 64, M - 1) * (unsigned)lda * 2u + cbyte[u];   // clamp: rows >= M never stored
-#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(slot + u * 1024), 16, (int)v, Tk * 128, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(slot + u * 1024), 16, (int)voff_w[h][u], bnS * ldw * 2 + Tk * 128, 0, 0);
@@ -461,17 +430,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
-#ifdef VV_GEMM_ABLATE
-        if (e.dbg & 2048) {          // timing only: the cluster twice (32 MFMAs per barrier interval, same loads / reads / barriers)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
-        }
-#endif
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -516,37 +474,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         bar(); cluster(1, 0); bar();
     };
 
-#ifdef VV_GEMM_P2
-    // P2: TWO barrier intervals per K-tile half instead of four -- each C segment is 32 MFMAs (two quadrants), so the ~65 cycles
-    // an interval loses around its barriers (measured: doubling the MFMAs per interval adds exactly their pipe time) are paid 4x
-    // per K-tile, not 8x.
-    //   PA(T): read Wn0, Wn1, Am0 of T | stage Wn0, Wn1, Am0 of T+1 | quadrants (m0,n0) (m0,n1)
-    //   PB(T): read Am1 of T            | stage Am1 of T+1           | quadrants (m1,n1) (m1,n0)
-    // A slot is restaged three intervals after this group read it (the other group reads one interval later and has its data
-    // in registers by the end of its own C segment); data is read two barriers after the staging wave's counted wait.
-    // Prefetch distance: one K-tile.  Counted waits: end of L(PA) needs Am1(T) (staged PB(T-1)): vmcnt(6); end of L(PB) needs
-    // the PA set of T+1: vmcnt(2).  The FIRST K-tile of a tile stages nothing in PA (its T+1 set was staged at the start of
-    // the previous tile's epilogue, ahead of the 16 output stores, or in the prologue): with G1's counted stores its waits are
-    // vmcnt(6 + 16) and vmcnt(2 + 16), so the stores stay in flight for the whole first K-tile.
-    auto ktile2 = [&](auto first_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) {
-        constexpr bool first = decltype(first_c)::value;
-        const char* base = smem + par * (4 * UNIT);
-        const bool r1 = T + 1 >= nk;
-        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;
-        // ---- PA
-        read_w(0, base + 0 * UNIT);
-        read_w(1, base + 2 * UNIT);
-        read_a(base + 1 * UNIT);
-        if constexpr (!first) { stage(T0{}, bm1, bn1, t1, par ^ 1); stage(T2{}, bm1, bn1, t1, par ^ 1); stage(T1{}, bm1, bn1, t1, par ^ 1); }
-        if constexpr (first && G1) VV_WAITVM(22); else VV_WAITVM(6);
-        bar(); cluster(0, 0); cluster(0, 1); bar();
-        // ---- PB
-        read_a(base + 3 * UNIT);
-        stage(T3{}, bm1, bn1, t1, par ^ 1);
-        if constexpr (first && G1) VV_WAITVM(18); else VV_WAITVM(2);
-        bar(); cluster(1, 1); cluster(1, 0); bar();
-    };
-#endif
 
     // prologue = phases -6..-1 of the staging schedule for this block's first tile
     {
@@ -554,13 +481,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         entry(0, bm0, bn0, part0, nk0);
         const int kb0 = part0 * nk0;
         stage(T0{}, bm0, bn0, kb0, 0); stage(T1{}, bm0, bn0, kb0, 0); stage(T2{}, bm0, bn0, kb0, 0); stage(T3{}, bm0, bn0, kb0, 0);
-#ifdef VV_GEMM_P2
-        stage(T0{}, bm0, bn0, kb0 + 1, 1); stage(T2{}, bm0, bn0, kb0 + 1, 1); stage(T1{}, bm0, bn0, kb0 + 1, 1);      // the PA set of K-tile 1
-#else
         stage(T0{}, bm0, bn0, kb0 + 1, 1); stage(T1{}, bm0, bn0, kb0 + 1, 1);
-#endif
     }
-#ifdef VV_GEMM_G1
     float bias_nx = 0.f, gate_nx = 0.f;
     if constexpr (G1) {
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -573,12 +495,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         if (e.bias) bias_nx = e.bias[bn0 + wc * 64 + lane];              // compiler-counted: waited for before the loop
         if constexpr (MODE == MODE_GATE_STORE) gate_nx = e.gate[bn0 + wc * 64 + lane];
     }
-#endif
-#ifdef VV_GEMM_P2
-    VV_WAITVM(6);                                              // K-tile 0 complete (at most the K-tile 1 set still in flight)
-#else
     VV_WAITVM(8);
-#endif
     bar();
     if (g == 1) bar();                                         // stagger group 1 by one segment
 
@@ -590,7 +507,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         const bool last = it + 1 == n_my;
         entry(last ? it : it + 1, bm_n, bn_n, part_n, nk_n);
         const int kb = part * nk, kb_n = part_n * nk_n;
-#ifdef VV_GEMM_G1
         // K parts 1.. write to the partial buffer [ks - 1][M - row0][ldc] (the consumer adds the parts: vv_layernorm's delta
         // tails).  The resource base is moved back by row0 rows so that the same global-row offsets address it; only rows
         // >= row0 are ever stored through it.
@@ -602,22 +518,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                                                          (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
             }
         }
-#endif
         // accumulators start at the bias (feature-only), so the epilogue has no bias pass
-#ifdef VV_GEMM_G1
         const float bias_cur = part == 0 ? bias_nx : 0.f;          // the bias belongs to K part 0 only
-#endif
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef VV_GEMM_G1
                 if constexpr (G1) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) b4[j] = lane_get(bias_cur, nh * 32 + ni * 16 + cq * 4 + j);
                 } else
-#endif
                 if (e.bias && part == 0) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
@@ -627,14 +538,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // first K-tile after a full bf16 tile store (every wave issued exactly 16 stores): leave those stores in flight
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
-#ifdef VV_GEMM_P2
-        ktile2(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
-        ++G;
-        for (int T = 1; T < nk; ++T, ++G) ktile2(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
-        // the PA set of the NEXT tile's K-tile 1: its slots (the parity of the K-tile just finished) were last read three
-        // intervals ago; issued here, ahead of the 16 stores, it is older than them for the first K-tile's counted waits
-        stage(T0{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1); stage(T2{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1); stage(T1{}, bm_n, bn_n, kb_n + 1, (G & 1) ^ 1);
-#else
         if constexpr (G1) {
             ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);             // 16 stores (real or dropped) always precede a tile
         } else if constexpr (MODE == MODE_STORE) {
@@ -645,10 +548,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         }
         ++G;
         for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
-#endif
-        stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && !VV_DBG(e) && bm + 256 <= M && bn + 256 <= e.n_store;
+        stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && bm + 256 <= M && bn + 256 <= e.n_store;
 
-#ifdef VV_GEMM_E2
         // E2: both groups run their epilogue in the SAME barrier interval.  With the plain one-segment stagger, group 0's epilogue
         // overlaps only group 1's last MFMA cluster and group 1's epilogue only group 0's first cluster of the next tile: the two
         // ~3 us epilogues of a tile run back to back with the matrix pipe idle.  Group 0 therefore waits out one interval here
@@ -656,7 +557,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (Letting group 0 run its pre-pass and first store pass inside that interval instead of idling was measured: QKV +1.4 %,
         // the rest flat -- profiles/r02/gemm_notes.md.)
         if (g == 0) bar();
-#endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
             // x * sigmoid(2u) == 0.5 x (1 + tanh u);  sigmoid(w) = 1 / (1 + 2^(-w log2 e)): the -log2(e) is folded into the constants
@@ -688,15 +588,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-#ifdef VV_GEMM_G1
                     float4 gt;
                     if constexpr (G1) {
                         gt.x = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 0); gt.y = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 1);
                         gt.z = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 2); gt.w = lane_get(gate_nx, nh * 32 + ni * 16 + cq * 4 + 3);
                     } else gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
-#else
-                    const float4 gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
-#endif
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -711,7 +607,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
             // chunk index XOR (row & 7)) so that global stores are whole 128-byte rows.  The unit slots are NOT
             // touched: the next tile's first units are landing there.
             char* stg = smem + 8 * UNIT + wave * 4096;
-            if (!(VV_DBG(e) & 512))
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int mh = ps >> 1;
@@ -781,21 +676,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                 for (int q = 0; q < 4; ++q) {
                     const int lr = q * 8 + (lane >> 3);
                     const int ch = lane & 7;
-#ifdef VV_GEMM_G2
-                    // hipcc drains vmcnt(0) before a ds_read that follows LDS-DMA in flight (it cannot prove the DMA targets another
-                    // region): the ring's prefetch for the next tile would be waited for at every epilogue.  An asm read-back is not
-                    // part of that bookkeeping; its own lgkmcnt wait sits in the same statement (cdna guide 5.7 item 1, form i).
-                    uint4 val;
-                    {
-                        const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
-                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(val) : "v"(la) : "memory");
-                    }
-#else
                     const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
-#endif
                     const int m = bm + g * 128 + ps * 32 + lr;
                     const int n0 = bn + wc * 64 + ch * 8;
-#ifdef VV_GEMM_G1
                     if constexpr (G1) {
                         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
                         const u32x4 vv = {val.x, val.y, val.z, val.w};
@@ -806,17 +689,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         const unsigned soff = ((unsigned)row_first * (unsigned)ldc + (unsigned)(bn + wc * 64)) * 2u;
                         __builtin_amdgcn_raw_buffer_store_b128(vv, rs_p, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
                     } else
-#endif
-                    if (m < M && n0 < e.n_store && !(VV_DBG(e) & 128)) {
-                        if (VV_DBG(e) & 1024) *(uint4*)((bf16*)C + (size_t)m * ldc + n0) = val;
-                        else {   // streamed once, read by the next kernel from HBM anyway
-                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                            const u32x4 vv = {val.x, val.y, val.z, val.w};
-                            __builtin_nontemporal_store(vv, (u32x4*)((bf16*)C + (size_t)m * ldc + n0));
-                        }
+                    if (m < M && n0 < e.n_store) {   // streamed once, read by the next kernel from HBM anyway
+                        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                        const u32x4 vv = {val.x, val.y, val.z, val.w};
+                        __builtin_nontemporal_store(vv, (u32x4*)((bf16*)C + (size_t)m * ldc + n0));
                     }
                 }
-#ifdef VV_GEMM_G1
                 if constexpr (G1) {
                     // next tile's bias / gate, issued behind the first pass's 4 stores (hipcc drains vmcnt before the first
                     // read-back of the staging region: the prefetch must not sit in front of that wait) and ahead of the other 12
@@ -825,13 +703,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         if constexpr (MODE == MODE_GATE_STORE) gate_nx = load_async(e.gate + bn_n + wc * 64 + lane);
                     }
                 }
-#endif
             }
-#ifdef VV_GEMM_G1
             // the two prefetch loads sit in front of the last 12 stores: after this wait they have landed (those stores stay in
             // flight), and naming the registers keeps every use / copy of them below it
             if constexpr (G1) asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_nx), "+v"(gate_nx)::"memory");
-#endif
         } else {
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
@@ -852,9 +727,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         }
                 }
         }
-#ifdef VV_GEMM_E2
         if (g == 1) bar();                                     // group 1 falls one segment behind again
-#endif
     }
     if (g == 0) bar();                                         // balance group 1's extra barrier
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
@@ -895,7 +768,6 @@ struct KernelSetup {
 // Returns parts = 0 when there is nothing to gain (no remainder, remainder too large, K too short).
 void tail_plan(int M, int N, int K, int n_cu, int* row0, int* parts) {
     *row0 = 0; *parts = 0;
-#ifdef VV_GEMM_G1
     if (N % 256 || K % 64 || M < 4096) return;
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256, total = m_tiles * n_tiles;
     const int rounds = total / n_cu;
@@ -907,7 +779,6 @@ void tail_plan(int M, int N, int K, int n_cu, int* row0, int* parts) {
     const int tail_tiles = (m_tiles - main_panels) * n_tiles, nk = K >> 6;
     for (int ks = 4; ks >= 2; ks >>= 1)
         if (tail_tiles * ks <= n_cu && nk % ks == 0 && nk / ks >= 2) { *row0 = main_panels * 256; *parts = ks; return; }
-#endif
 }
 
 int device_cus() {
@@ -962,11 +833,10 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
     if constexpr (sizeof(T) == 2) {
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
-        if (big && !(VV_DBG(e) & 12) && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
+        if (big && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
     if (e.ks > 1) return hipErrorInvalidValue;                 // a split-K tail exists in the persistent kernel only (vvk_gemm checks)
-    if (big && (VV_DBG(e) & 4)) return launch_t<T, MODE, To, 1>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
@@ -1004,12 +874,6 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
     }
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
-#ifdef VV_GEMM_ABLATE
-    {   // ablation build only (never the shipped library): bits from the environment, read once per process
-        static const int dbg_env = [] { const char* d = getenv("VV_GEMM_DBG"); return d ? atoi(d) : 0; }();
-        e.dbg = dbg_env;
-    }
-#endif
     if (g->mode == MODE_QKV_ROPE && !g->rope_pos && (unsigned long long)g->M * (unsigned long long)e.seq_n >= ((unsigned long long)1 << 32)) {
         *err = "gemm: rope without a position table needs M * seq_n < 2^32"; return -22;
     }

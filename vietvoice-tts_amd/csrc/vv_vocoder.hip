@@ -19,16 +19,8 @@ namespace {
 
 constexpr int VT = 256;       // time steps per workgroup
 
-// LeakyReLU.  -DVV_VOC_DIET builds the round-2 experiment (max(x, slope x) in two instructions + an interior fast path without
-// per-element range logic in the staging loops): bit-identical PCM, but the conv class got SLOWER at the headline batch, 191.1 ->
-// 204.0 ms (profiles/r02/vocoder_notes.md), so the round-1 staging stays the default.
-#ifdef VV_VOC_DIET
-__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); }     // needs 0 < slope <= 1 (host-checked)
-#define VV_VOC_INTERIOR(expr) (expr)
-#else
+// LeakyReLU (a two-instruction max form and an interior staging fast path measured slower: profiles/r02/vocoder_notes.md)
 __device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.f ? x : x * slope; }
-#define VV_VOC_INTERIOR(expr) false
-#endif
 
 // KW: taps.  TRANSPOSED: polyphase ConvTranspose (KW must be 2).  VCI: input channels per K chunk.
 // RT: 32-row MFMA tiles per wave (2 -> 64 rows per workgroup, 1 -> 32 rows for the narrow last stage).
@@ -78,18 +70,6 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
         __syncthreads();
         // ---- stage the input window: xs[c][i] = lrelu(in[c0+c][q0 - L4 + i]), zero outside [0, lin); wave w takes
         // channels w, w+4, ...; aligned float4 loads wherever the four samples are inside the row
-        // interior workgroups (window inside [0, len), aligned rows, whole chunk live): no per-element range logic at all
-        const bool interior = VV_VOC_INTERIOR(vec_ok && q0 - L4 >= 0 && q0 - L4 + xw_pad <= lin && c0 + VCI <= Cin);
-        if (interior) {
-            for (int c = wave; c < VCI; c += 4) {
-                const float* row = inb + (size_t)(c0 + c) * T_in + (q0 - L4);
-                for (int i4 = lane; i4 < xw4; i4 += 64) {
-                    float4 v = *(const float4*)(row + i4 * 4);
-                    v.x = lrelu(v.x, pre_slope); v.y = lrelu(v.y, pre_slope); v.z = lrelu(v.z, pre_slope); v.w = lrelu(v.w, pre_slope);
-                    *(float4*)(xs + c * xw_pad + i4 * 4) = v;
-                }
-            }
-        } else
         for (int c = wave; c < VCI; c += 4) {
             const bool live = c0 + c < Cin;
             const float* row = inb + (size_t)(c0 + c) * T_in;
@@ -268,17 +248,6 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
     zero_acc();
     for (int c0 = 0; c0 < C; c0 += VCI) {
         __syncthreads();
-        const bool interior = VV_VOC_INTERIOR(vec_ok && q0 - A >= 0 && q0 - A + xw_pad <= lin);          // no per-element range logic (see conv_mfma_kernel)
-        if (interior) {
-            for (int c = wave; c < VCI; c += 4) {
-                const float* row = yb + (size_t)(c0 + c) * T + (q0 - A);
-                for (int i4 = lane; i4 < xw4; i4 += 64) {
-                    float4 v = *(const float4*)(row + i4 * 4);
-                    v.x = lrelu(v.x, slope); v.y = lrelu(v.y, slope); v.z = lrelu(v.z, slope); v.w = lrelu(v.w, slope);
-                    *(float4*)(xs + c * xw_pad + i4 * 4) = v;
-                }
-            }
-        } else
         for (int c = wave; c < VCI; c += 4) {
             const float* row = yb + (size_t)(c0 + c) * T;
             for (int i4 = lane; i4 < xw4; i4 += 64) {
