@@ -70,11 +70,9 @@ def make_inputs(spec: ModelSpec, B: int, rank: int, device):
     return d, N
 
 
-def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, device):
-    """BASELINE configs[3]: 32*world units, text 64-512 tokens, reference clips 3-9 s, LPT-sharded by frame cost;
-    this rank's shard becomes one ragged batch (per-item lengths on the device, masks in every kernel)."""
-    g = torch.Generator().manual_seed(SEED + 77)
-    total = per_rank * world
+def mixed_unit_plan(spec: ModelSpec, total: int, g: torch.Generator):
+    """The seeded unit list of BASELINE configs[3]: per unit text tokens (64-512), reference-clip samples (3-9 s), reference /
+    generated / total frames by the reference's rules.  Draws from g (the first two draws of make_mixed_inputs' stream)."""
     toks = torch.randint(64, 513, (total,), generator=g)
     secs = 3.0 + 6.0 * torch.rand(total, generator=g)
     samples = (secs * spec.sample_rate).to(torch.int64) // 256 * 256
@@ -82,6 +80,15 @@ def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, dev
     gen_frames = torch.clamp((toks.float() * 0.62 * 6.48).to(torch.int64), min=94)     # ~62 % of the ids are target text
     gen_frames = torch.minimum(gen_frames, 1875 - ref_frames)                            # 20 s chunk cap of the reference
     frames = (ref_frames + gen_frames).tolist()
+    return toks, samples, ref_frames, gen_frames, frames
+
+
+def make_mixed_inputs(spec: ModelSpec, per_rank: int, rank: int, world: int, device):
+    """BASELINE configs[3]: 32*world units, text 64-512 tokens, reference clips 3-9 s, LPT-sharded by frame cost;
+    this rank's shard becomes one ragged batch (per-item lengths on the device, masks in every kernel)."""
+    g = torch.Generator().manual_seed(SEED + 77)
+    total = per_rank * world
+    toks, samples, ref_frames, gen_frames, frames = mixed_unit_plan(spec, total, g)
     mine = sharding.shard_units([sharding.unit_cost(f, spec.dim) for f in frames], world)[rank]
     batches = []
     pad_frac = float(os.environ.get("VV_BENCH_PAD_FRAC", "1.0"))     # 1.0 = one ragged batch per rank (rows are packed on the device)
@@ -306,10 +313,11 @@ def main():
     ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     # HBM-side bytes per launch: PMC counters cannot be read from inside the process, so the figure comes from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py).  Passes over THIS command die inside the profiler
-    # (profiles/r02/gemm_notes.md, stack + maps committed), so the r02 file is taken over tools/gemm_ab.py at the block's four shapes.
+    # (profiles/r02/gemm_notes.md, stack + maps committed), so the file is taken over tools/gemm_ab.py at the block's four shapes; the
+    # file names the program it was taken over ("how_short"), and that string is what traffic_source reports.
     traffic, traffic_src = None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for rel in ("profiles/r02/bench_pmc_traffic.json", "profiles/r02/gemm_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
+    for rel in ("profiles/r03/gemm_pmc_traffic.json", "profiles/r02/gemm_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
         tf = os.path.join(here, rel)
         if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
             with open(tf) as fh:

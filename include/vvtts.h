@@ -166,7 +166,9 @@ typedef struct vv_gemm_args {
 VV_API int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 /* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the
  * gate-store form can split the K range of the last row panels `parts` ways so that the remainder costs 1/parts of a round.
- * Returns the plan for this shape on the current device: rows >= row0 are split `parts` ways (parts = 0: nothing to gain). */
+ * Returns the plan for this shape (contiguous operands: lda = ldw = K, ldc = N) on the context's device: rows >= row0 are split
+ * `parts` ways; parts = 0: nothing to gain, or an operand of 2 GiB or more (those take the plain-pointer kernel, which has no
+ * tail).  ctx may be NULL (the process's current device, 256 CUs when there is none). */
 VV_API int vv_gemm_tail_plan(vv_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts);
 
 typedef struct vv_attn_args {

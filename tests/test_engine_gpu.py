@@ -267,3 +267,84 @@ def test_bench_two_rank_branch_over_gloo():
     assert d["weight_pack_and_broadcast_ms"] > 0 and "cpu_baseline" not in d         # cpu_baseline is an N = 1 leg
     per_rank_audio = 4 * 1037 * 256 / 24000.0
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank_audio) < 0.02 * per_rank_audio      # value = SUM of audio over ranks / MAX time
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_concurrent_callers_on_one_engine(tmp_path, graph):
+    """The REST layer enters one engine from worker threads (/root/reference/vietvoicetts/api/tts_engine.py:64-91: config.speed is
+    set, `synthesize_to_bytes` runs under anyio.to_thread, speed is restored; concurrent test: /root/reference/tests/
+    test_api_integration.py:148-176).  Four threads call `synthesize` on ONE HIP engine -- two voices, two speeds set by mutating
+    `config.speed` the way the REST layer does.  No exception, no deadlock; and because the engine serialises the GPU work, every
+    result must equal the same request replayed SERIALLY on a fresh engine in the order in which the threads got the lock (the
+    seeded noise stream makes the order matter: it is recorded, not assumed)."""
+    import threading
+    reqs = [dict(text="Xin chào các bạn, hôm nay trời đẹp quá.", gender="female", speed=0.9),
+            dict(text="Chúng ta cùng nhau đi dạo quanh hồ nhé.", gender="male", speed=1.2),
+            dict(text=LONG, gender="female", speed=1.2),
+            dict(text="Cảm ơn rất nhiều.", gender="male", speed=0.9)]
+    eng = _engine(tmp_path, max_batch_chunks=2, use_hip_graph=graph)
+    order, results, errors = [], {}, []
+    tl = threading.local()
+    mut = threading.Lock()                  # the REST layer's event loop is single-threaded: its config mutations do not interleave
+    orig_select, orig_prepare = eng.model_session_manager.select_sample, eng._prepare_inputs
+
+    def select(*a, **k):                    # called right after `synthesize` has read config.speed
+        tl.entered.set()
+        return orig_select(*a, **k)
+
+    def prepare(*a, **k):                   # called under the engine lock: the order of GPU work
+        order.append(tl.rid)
+        return orig_prepare(*a, **k)
+    eng.model_session_manager.select_sample, eng._prepare_inputs = select, prepare
+
+    def worker(rid, entered):
+        tl.rid, tl.entered = rid, entered
+        try:
+            results[rid] = eng.synthesize(reqs[rid]["text"], gender=reqs[rid]["gender"])[0]
+        except Exception as e:            # noqa: BLE001
+            errors.append((rid, repr(e)))
+            entered.set()
+    threads = []
+    for rid, r in enumerate(reqs):
+        with mut:
+            entered = threading.Event()
+            saved, eng.config.speed = eng.config.speed, r["speed"]
+            t = threading.Thread(target=worker, args=(rid, entered), name=f"req{rid}")
+            t.start()
+            assert entered.wait(60)
+            eng.config.speed = saved
+        threads.append(t)
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive(), "deadlock: a caller never returned"
+    eng.cleanup()
+    assert not errors, errors
+    assert sorted(order) == [0, 1, 2, 3] and len(results) == 4
+    # serial replay in the recorded order on a fresh engine (same seed -> same noise stream)
+    ser = _engine(tmp_path, max_batch_chunks=2, use_hip_graph=graph)
+    for rid in order:
+        ser.config.speed = reqs[rid]["speed"]
+        w, _ = ser.synthesize(reqs[rid]["text"], gender=reqs[rid]["gender"])
+        assert w.shape == results[rid].shape and np.array_equal(w, results[rid]), f"request {rid} differs from its serial replay"
+    ser.cleanup()
+    assert len({r.size for r in results.values()}) >= 3           # different texts / speeds really produced different audio
+
+
+def test_decode_graph_cache_is_bounded(tmp_path):
+    """ADVICE r02: captured decode graphs are kept in an LRU of `decode_graph_cache_entries` entries sharing ONE workspace block;
+    a service with varied reference clips cannot grow HBM without limit.  Results do not depend on eviction."""
+    from vietvoice_tts_amd.runtime import DecodeGraphCache
+    texts = ["Xin chào.", "Xin chào các bạn, hôm nay trời đẹp quá, chúng ta đi dạo nhé.", LONG, "Cảm ơn rất nhiều, hẹn gặp lại các bạn vào ngày mai nhé."]
+    a = _engine(tmp_path, max_batch_chunks=2, use_hip_graph=True, decode_graph_cache_entries=2)
+    wa = [a.synthesize(t)[0] for t in texts + texts]
+    c = a._decode_graphs
+    assert isinstance(c, DecodeGraphCache) and len(c) <= 2 and c.evictions >= 1 and c.misses >= 3
+    blocks = {g.ws.data_ptr() for g in c._graphs.values()}
+    assert len(blocks) == 1, "the live graphs share one workspace block"
+    a.cleanup()
+    b = _engine(tmp_path, max_batch_chunks=2, use_hip_graph=True, decode_graph_cache_entries=64)
+    wb = [b.synthesize(t)[0] for t in texts + texts]
+    assert b._decode_graphs.evictions == 0
+    b.cleanup()
+    for x, y in zip(wa, wb):
+        assert np.array_equal(x, y)

@@ -21,7 +21,8 @@ is not attainable by ANY fp32 implementation of this network and the assertions 
     ~1e-6 of the spectral peak; bins holding only that noise sit near the 1e-5 clamp where the LOG amplifies it):
     |mel_hip - mel_f64| <= 1e-6 peak + 1e-4 mel.
   * fp32 vocoder: waveform |d| <= 3e-5 of full scale (one LSB = 3.05e-5), PCM within +-1 LSB of the float64 oracle's PCM.
-  * bf16 acoustic: state RMSE <= 2 % of the state RMS (8-bit mantissa operands, fp32 accumulate and residual stream).
+  * bf16 acoustic (8-bit mantissa operands, fp32 accumulate and residual stream): every bound is 2 x the figure measured on the
+    round-2 build (state rmse/rms 3.7e-3 / 6.2e-3 after the two steps, waveform 6.2e-3, batch-vs-alone 4.8e-3 / 5.2e-3).
 """
 import os
 import sys
@@ -205,11 +206,13 @@ def test_bf16_full_size_close_to_oracle_and_b32_properties(full_case):
         got, ref = st1[st][0].cpu().double(), c["xs"][st + 1]
         rmse = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         print(f"\n[full bf16 B=1] Euler step {st}: state rmse/rms {rmse:.3e}, max abs err {float((got - ref).abs().max()):.3e}")
-        assert rmse < 2e-2, (st, rmse)
+        # measured 3.7e-3 / 6.2e-3 after step 0 / 1 (round 2, same inputs): bound = 2 x measured, so a regression that doubles the
+        # bf16 error fails
+        assert rmse < (7.5e-3, 1.25e-2)[st], (st, rmse)
     n = c["wave"].numel()
     wr = float((wave1[0, :n].cpu().double() - c["wave"]).pow(2).mean().sqrt() / c["wave"].pow(2).mean().sqrt())
     print(f"[full bf16 B=1] waveform rmse/rms vs the fp32 oracle {wr:.3e}")
-    assert wr < 0.1
+    assert wr < 1.25e-2                      # measured 6.2e-3; 2 x
     # ---- the headline batch
     _, st32, (pcm32, len32, wave32) = _run(eng, _dev(c["d"], slice(0, B_HEAD)), c["N"], bench.GEN_FRAMES)
     assert int(len32.sum()) == B_HEAD * n and bool((len32 == n).all())             # what bench.py asserts, per item
@@ -223,8 +226,8 @@ def test_bf16_full_size_close_to_oracle_and_b32_properties(full_case):
     wd = float((wave32[0, :n] - wave1[0, :n]).double().pow(2).mean().sqrt() / wave1[0, :n].double().pow(2).mean().sqrt())
     print(f"[full bf16 B=32] item 0 in the batch vs alone: state rmse/rms {d0:.3e}, waveform rmse/rms {wd:.3e}; vs float64 oracle rmse/rms {rmse32:.3e}")
     # M = 102,400 rows take the persistent 256x256 GEMM, M = 3,200 the 128x128 kernel: different bf16 rounding points, same tolerance class
-    assert d0 < 1e-2 and wd < 0.05
-    assert rmse32 < 2e-2
+    assert d0 < 1e-2 and wd < 1.05e-2                                              # measured 4.8e-3 / 5.2e-3; 2 x
+    assert rmse32 < 1.25e-2                                                        # measured 6.2e-3; 2 x
     # items differ (different clips / ids / noise): the batch is not one utterance repeated
     assert float((x32[1] - x32[0]).abs().max()) > 1e-2
     # the split-K tail of the FF2 GEMM (default option 2; 1 adds the out-projection; this batch has 1,600 tiles = 6.25 rounds, so it is taken):

@@ -351,3 +351,37 @@ def test_crossfade_stream_equals_buffered_join_including_clipped_chunks():
         assert got.shape == want.shape and np.array_equal(got, want)
         if len(ws) > 2 and dur > 0:
             assert blocks[0].size > 0 or ws[0].size <= int(dur * sr)       # audio really is emitted before the last chunk
+
+
+def test_split_k_tail_planner_agrees_with_the_launcher_on_large_operands():
+    """vv_gemm_tail_plan must apply the persistent kernel's operand-size condition (buffer resources carry a 31-bit
+    num_records) -- otherwise bf16 vv_transformer_steps rejects packed batches of >= 262,144 rows that max_rows_per_call admits.
+    Checked without a GPU: ctx = NULL plans for 256 CUs."""
+    import ctypes as C
+    from vietvoice_tts_amd import runtime as rt
+    lib = rt.load_library()
+    r0, parts = C.c_int32(-1), C.c_int32(-1)
+    # the headline shape: FF2 (K = 2048) and out-projection (K = 1024) of M = 102,400 rows: 6.25 rounds -> 16-panel tail, 4 parts
+    for K in (2048, 1024):
+        assert lib.vv_gemm_tail_plan(None, 102400, 1024, K, C.byref(r0), C.byref(parts)) == 0
+        assert (r0.value, parts.value) == (98304, 4)
+    # an activation operand of >= 2 GiB (M * lda * 2 bytes) takes the plain-pointer kernel, which has no tail: parts must be 0
+    assert lib.vv_gemm_tail_plan(None, 300000, 1024, 4096, C.byref(r0), C.byref(parts)) == 0
+    assert (r0.value, parts.value) == (0, 0)
+    assert 300000 * 4096 * 2 >= 1 << 31
+    # just below the limit the plan is whatever the round arithmetic says, and is stable
+    assert lib.vv_gemm_tail_plan(None, 262143, 1024, 4096, C.byref(r0), C.byref(parts)) == 0
+    a = (r0.value, parts.value)
+    assert lib.vv_gemm_tail_plan(None, 262143, 1024, 4096, C.byref(r0), C.byref(parts)) == 0 and a == (r0.value, parts.value)
+    assert lib.vv_gemm_tail_plan(None, 0, 1024, 1024, C.byref(r0), C.byref(parts)) == -22
+
+
+def test_decode_graph_cache_buckets():
+    from vietvoice_tts_amd.runtime import DecodeGraphCache
+    assert DecodeGraphCache.bucket(1600, 1037) == (1664, 1088)
+    assert DecodeGraphCache.bucket(1664, 1664 - 563) == (1664, 1152)
+    assert DecodeGraphCache.bucket(128, 500) == (128, 128)            # generated frames never exceed the frame bucket
+    assert DecodeGraphCache.bucket(129, 1) == (256, 64)
+    # nearby reference clips (5.90 s .. 6.10 s) share one key
+    keys = {DecodeGraphCache.bucket(1664, 1664 - (int(s * 24000) // 256 + 1)) for s in (5.9, 5.95, 6.0, 6.05, 6.1)}
+    assert len(keys) == 1

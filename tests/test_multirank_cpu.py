@@ -91,3 +91,29 @@ def test_plan_batches_covers_units_and_bounds_padding():
             assert waste <= 0.05 + 1e-9 or len(b) <= 4 or len(b) == mx
     assert plan_batches([], 8) == [] and plan_batches([100], 8) == [[0]]
     assert plan_batches([1600] * 32, 32) == [list(range(32))]                       # the headline workload stays one batch
+
+
+def test_configs3_units_shard_evenly_over_8_ranks():
+    """BASELINE configs[3] ("batch=256 mixed-length ... sharded across 8xMI355X") without the hardware: the 256 seeded units of
+    bench.make_mixed_inputs (its own generator, `bench.mixed_unit_plan`) through `shard_units(.., 8)` -- every unit on exactly one
+    rank, 32 units per rank, cost imbalance <= 1 % (measured +-0.1 %), and the per-rank row counts within the packed-row limit of
+    one vv_transformer_steps call.  The 8-GPU run itself is UNMEASURED ON HARDWARE (no 8-GPU node in rounds 1-3)."""
+    import bench
+    from vietvoice_tts_amd import sharding
+    from vietvoice_tts_amd.model_spec import ModelSpec
+    spec = ModelSpec.full()
+    g = torch.Generator().manual_seed(bench.SEED + 77)
+    toks, samples, ref_frames, gen_frames, frames = bench.mixed_unit_plan(spec, 256, g)
+    assert int(toks.min()) >= 64 and int(toks.max()) <= 512 and 3 * 24000 - 256 <= int(samples.min()) and int(samples.max()) <= 9 * 24000
+    assert max(frames) <= 1875 and min(int(v) for v in gen_frames) >= 94          # the reference's 20 s chunk cap, min_target_duration
+    costs = [sharding.unit_cost(f, spec.dim) for f in frames]
+    shards = sharding.shard_units(costs, 8)
+    assert sorted(u for s in shards for u in s) == list(range(256))
+    assert [len(s) for s in shards] == [32] * 8
+    loads = [sum(costs[u] for u in s) for s in shards]
+    mean = sum(loads) / 8
+    assert max(abs(l - mean) / mean for l in loads) <= 0.01
+    row_cap = ((1 << 31) - 1) // (2 * 3 * spec.dim * 2)                            # HipSynth.max_rows_per_call, bf16
+    assert max(sum(frames[u] for u in s) for s in shards) <= row_cap
+    # the same plan on every rank: sharding is a pure function of the seeded list
+    assert sharding.shard_units(costs, 8) == shards

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""HBM-side bytes per launch from rocprofv3 PMC passes over bench.py (MI355X_MICROARCH.md, HBM section).
+"""HBM-side bytes per launch from rocprofv3 PMC passes (MI355X_MICROARCH.md, HBM section) over the program named in the
+optional 4th argument (default: "bench.py itself"; tools/profile_gemm_pmc.sh passes "tools/gemm_ab.py at the block's four shapes
+(bench.py passes fault inside librocprofiler-sdk)" -- the string goes into the bench line's traffic_source, so the record says what
+was measured).
 
 FETCH_SIZE and WRITE_SIZE need separate passes (TCC has 4 slots: 3 + 2).  Run, program directly after `--`:
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r02/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
@@ -38,6 +41,7 @@ def short(name):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    program = sys.argv[4] if len(sys.argv) > 4 else "bench.py itself"
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     rows, tot = [], {"launches": 0, "read": 0.0, "write": 0.0}
     for name in sorted(set(fetch) | set(write)):
@@ -51,11 +55,12 @@ def main():
             tot["read"] += read_b
             tot["write"] += write_b
     rows.sort(key=lambda r: -(r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"])
-    doc = {"kernel": "gemm_pp_kernel (K6, all epilogue modes), averaged over the launches of one bench.py step",
+    doc = {"kernel": f"gemm_pp_kernel (K6, all epilogue modes), averaged over its launches in {program}",
+           "program": program,
            "launches": tot["launches"],
            "traffic_bytes_per_launch": (tot["read"] + tot["write"]) / max(tot["launches"], 1),
            "read_bytes_per_launch": tot["read"] / max(tot["launches"], 1), "write_bytes_per_launch": tot["write"] / max(tot["launches"], 1),
-           "how_short": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py itself, FETCH_SIZE x2 (gfx950), per launch",
+           "how_short": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over {program}, FETCH_SIZE x2 (gfx950), per launch",
            "how": __doc__.strip().splitlines()[0] + "  FETCH_SIZE doubled, KiB -> bytes; counted at the L2<->fabric boundary (Infinity-Cache hits included).",
            "per_kernel": rows[:40]}
     os.makedirs(os.path.dirname(out), exist_ok=True)

@@ -3,7 +3,7 @@
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over tools/gemm_ab.py (program directly after `--`).
 # Used because the same passes over bench.py die inside librocprofiler-sdk (profiles/r02/pmc_fetch_sigsegv_stack.txt).
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -13,7 +13,8 @@ LIB=$ROOT/vietvoice-tts_amd/libvvtts_hip.so
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/gpmc_fetch -- python3 $ROOT/tools/gemm_ab.py 1 $LIB > $OUT/gpmc_fetch.log 2>&1 || { tail -5 $OUT/gpmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/gpmc_write -- python3 $ROOT/tools/gemm_ab.py 1 $LIB > $OUT/gpmc_write.log 2>&1 || { tail -5 $OUT/gpmc_write.log; exit 1; }
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/gpmc_tcc -- python3 $ROOT/tools/gemm_ab.py 1 $LIB > $OUT/gpmc_tcc.log 2>&1 || { tail -5 $OUT/gpmc_tcc.log; exit 1; }
-python3 $ROOT/tools/pmc_traffic.py $OUT/gpmc_fetch $OUT/gpmc_write $OUT/gemm_pmc_traffic.json
+python3 $ROOT/tools/pmc_traffic.py $OUT/gpmc_fetch $OUT/gpmc_write $OUT/gemm_pmc_traffic.json \
+    "tools/gemm_ab.py at the block's four shapes, equal launch counts (bench.py passes fault inside librocprofiler-sdk: profiles/r02/pmc_fetch_sigsegv_stack.txt)"
 python3 - <<PY
 import csv, glob, collections
 per = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -59,6 +59,8 @@ class ModelConfig:
     model_spec: str = "full"                # architecture preset of a synthetic pack: full | small | tiny
     max_batch_chunks: int = 32              # chunks of one long text synthesised per GPU batch
     use_hip_graph: bool = False             # replay the vocoder step from a captured hipGraph (fixed frame buckets)
+    decode_graph_cache_entries: int = 8     # captured decode graphs kept per engine (least recently used beyond that)
+    decode_graph_cache_bytes: int = 16 << 30   # HBM the cache may pin (shared workspace + per-graph I/O buffers)
 
     def __post_init__(self):
         if not 0.1 <= self.speed <= 5.0:

@@ -47,7 +47,7 @@ class TTSEngine:
             from ..voice_bank import VoiceBank
             self.voice_bank = VoiceBank(self.model_session_manager.engine, self.config.sample_rate)
         self._lock = threading.Lock()
-        self._decode_graphs = {}
+        self._decode_graphs = None               # DecodeGraphCache, created with the first captured decode (use_hip_graph)
         self._last_plan = []
 
     def cleanup(self) -> None:
@@ -188,9 +188,11 @@ class TTSEngine:
             N = int(seq.max())
             t_gen = int((seq - ref_frames).max())
             if self.config.use_hip_graph:
-                # fixed frame buckets (multiples of 128) so that one captured vocoder graph serves every chunk group
-                N = (N + 127) // 128 * 128
-                t_gen = N - int(ref_frames.min())
+                # fixed buckets (frames to multiples of 128, generated frames to multiples of 64) so that one captured vocoder graph
+                # serves every chunk group and nearby reference-clip lengths; the decode masks every item by its own lengths
+                from ..runtime import DecodeGraphCache
+                Nb = DecodeGraphCache.bucket(N, 0)[0]
+                N, t_gen = DecodeGraphCache.bucket(Nb, Nb - int(ref_frames.min()))      # every chunk group of a text lands on one key
             noise = torch.zeros((B, N, spec.n_mel), dtype=torch.float32)
             for i, j in enumerate(idx):
                 noise[i, : seq[i]] = noise_blocks[j]
@@ -199,10 +201,9 @@ class TTSEngine:
                 pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, seq_len_host=seq)
                 x = noise.to(dev)
                 eng.transformer_steps(x, pre, 0, eng.n_steps)
-                key = (B, N, t_gen)
-                if key not in self._decode_graphs:
-                    self._decode_graphs[key] = eng.capture_decode(*key)
-                pcm, pcm_len = self._decode_graphs[key](x, pre["ref_signal_len"], pre["seq_len"])
+                if self._decode_graphs is None:
+                    self._decode_graphs = DecodeGraphCache(eng, self.config.decode_graph_cache_entries, self.config.decode_graph_cache_bytes)
+                pcm, pcm_len = self._decode_graphs.get(B, N, t_gen)(x, pre["ref_signal_len"], pre["seq_len"])
             else:
                 _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen,
                                                               gen_frames=[int(v) for v in (seq - ref_frames)], seq_len_host=seq)

@@ -444,8 +444,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     int tail_row0 = 0, tp_o = 0, tp_f = 0;
     if (c->split_k_tail && c->dt == VV_DTYPE_BF16) {
         int r0o = 0, r0f = 0;
-        if (c->split_k_tail == 1) vvk_gemm_tail_plan((int)R, D, D, &r0o, &tp_o);
-        vvk_gemm_tail_plan((int)R, D, FF, &r0f, &tp_f);
+        if (c->split_k_tail == 1) vvk_gemm_tail_plan((int)R, D, D, D, D, D, &r0o, &tp_o);          // (M, N, K, lda, ldw, ldc) of the launches below
+        vvk_gemm_tail_plan((int)R, D, FF, FF, FF, D, &r0f, &tp_f);
         if (tp_o && tp_f && r0o != r0f) tp_o = tp_f = 0;   // cannot happen (row0 is a function of M, N and the CU count); refuse rather than mix
         tail_row0 = tp_o ? r0o : r0f;
     }
@@ -784,9 +784,11 @@ int vv_prof_collect(vv_ctx* c, int64_t* launches, double* ms, double* flops, dou
 
 int vv_gemm(vv_ctx* c, const vv_gemm_args* a, void* st) { SINGLE(c, vvk_gemm(a, (hipStream_t)st, &m__)); }
 int vv_gemm_tail_plan(vv_ctx* c, int32_t M, int32_t N, int32_t K, int32_t* row0, int32_t* parts) {
-    if (!c || !row0 || !parts || M < 1 || N < 1 || K < 1) return c ? c->fail(-22, "vv_gemm_tail_plan: bad arguments") : -22;
-    HIPCHK(c, hipSetDevice(c->device));
-    vvk_gemm_tail_plan(M, N, K, row0, parts);
+    // ctx may be NULL: the plan for the process's current device (256 CUs when there is none), so that planner / launcher
+    // consistency can be checked without a GPU.  Operands are taken as contiguous (lda = ldw = K, ldc = N).
+    if (!row0 || !parts || M < 1 || N < 1 || K < 1) return c ? c->fail(-22, "vv_gemm_tail_plan: bad arguments") : -22;
+    if (c) HIPCHK(c, hipSetDevice(c->device));
+    vvk_gemm_tail_plan(M, N, K, K, K, N, row0, parts);
     return 0;
 }
 int vv_attention(vv_ctx* c, const vv_attn_args* a, void* st) { SINGLE(c, vvk_attention(a, (hipStream_t)st, &m__)); }

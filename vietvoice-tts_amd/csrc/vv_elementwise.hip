@@ -306,10 +306,14 @@ __global__ void dup_len_kernel(const int* __restrict__ seq_len, int* __restrict_
 //   row_start[2B] (conditional branch first), row_src[Rc] = b * N + t, row_pos[2 Rc] = t.
 __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__ seq_len, int B, int N, int Rc, int* __restrict__ row_start,
                                                          int* __restrict__ row_src, int* __restrict__ row_pos) {
+    // The table sizes (Rc, 2 Rc) and every launch shape come from the HOST copy of the lengths; the device copy is clamped to
+    // [0, N] and to the Rc rows that exist, so a device array that disagrees with the host one (stale tensor, wrong batch) cannot
+    // write past the tables -- it produces wrong audio for that call, never a stray store.
     const int b = blockIdx.x;
     int r0 = 0;
-    for (int i = 0; i < b; ++i) r0 += seq_len[i];            // B is at most a few hundred: a serial prefix per workgroup is cheaper than a scan
-    const int len = seq_len[b];
+    for (int i = 0; i < b; ++i) r0 += min(max(seq_len[i], 0), N);   // B is at most a few hundred: a serial prefix per workgroup is cheaper than a scan
+    r0 = min(r0, Rc);
+    const int len = min(min(max(seq_len[b], 0), N), Rc - r0);
     if (threadIdx.x == 0) { row_start[b] = r0; row_start[B + b] = Rc + r0; }
     for (int t = threadIdx.x; t < len; t += 256) {
         row_src[r0 + t] = b * N + t;

@@ -766,9 +766,17 @@ struct KernelSetup {
 // ways along K so that tail_tiles * parts entries fill (at most) one more, 1/parts as long, round.  Part 0 lands in C as
 // always; parts 1.. land in a partial buffer [parts - 1][M - row0][ldc] which the consumer adds (vv_ln_args.delta_tail).
 // Returns parts = 0 when there is nothing to gain (no remainder, remainder too large, K too short).
-void tail_plan(int M, int N, int K, int n_cu, int* row0, int* parts) {
+// The persistent kernel addresses its operands through buffer resources with a 31-bit num_records: operands of 2 GiB or more
+// take the plain-pointer kernels (64-bit addressing) instead.  The split-K tail exists in the persistent kernel only, so the
+// planner applies the same condition -- planner and launcher agree for every shape (M = 300,000, K = 4096: no tail).
+inline bool pp_fits(int M, int N, int K, int lda, int ldw, int ldc, size_t out_size, int act) {
+    return K >= 128 && act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31) &&
+           (size_t)M * ldc * out_size < ((size_t)1 << 31);
+}
+
+void tail_plan(int M, int N, int K, int lda, int ldw, int ldc, int n_cu, int* row0, int* parts) {
     *row0 = 0; *parts = 0;
-    if (N % 256 || K % 64 || M < 4096) return;
+    if (N % 256 || K % 64 || M < 4096 || !pp_fits(M, N, K, lda, ldw, ldc, 2, VV_ACT_NONE)) return;
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256, total = m_tiles * n_tiles;
     const int rounds = total / n_cu;
     if (rounds < 1 || total % n_cu == 0) return;
@@ -821,11 +829,6 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
     return hipGetLastError();
 }
 
-inline bool pp_fits(int M, int N, int K, int lda, int ldw, int ldc, size_t out_size, int act) {
-    return K >= 128 && act != VV_ACT_GELU_ERF && (size_t)M * lda * 2 < ((size_t)1 << 31) && (size_t)N * ldw * 2 < ((size_t)1 << 31) &&
-           (size_t)M * ldc * out_size < ((size_t)1 << 31);
-}
-
 template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                   hipStream_t st, int force_tile) {
@@ -844,7 +847,9 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
 }  // namespace
 
 // The split-K tail the persistent bf16 gate-store GEMM of this shape would take on the current device (parts = 0: none).
-void vvk_gemm_tail_plan(int M, int N, int K, int* row0, int* parts) { tail_plan(M, N, K, device_cus(), row0, parts); }
+void vvk_gemm_tail_plan(int M, int N, int K, int lda, int ldw, int ldc, int* row0, int* parts) {
+    tail_plan(M, N, K, lda, ldw, ldc, device_cus(), row0, parts);
+}
 
 // Host launcher.  Returns 0 or a negative errno-style code with a message in err.
 int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
@@ -867,7 +872,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (g->tail_parts) {
         int row0 = 0, parts = 0;
         if (g->mode == MODE_GATE_STORE && g->dtype == VV_BF16 && g->out_dtype == VV_BF16 && (g->tile == 0 || g->tile == 256))
-            if (pp_fits(g->M, g->N, g->K, g->lda, g->ldw, g->ldc, 2, g->act)) tail_plan(g->M, g->N, g->K, device_cus(), &row0, &parts);
+            if (g->act != VV_ACT_GELU_ERF) tail_plan(g->M, g->N, g->K, g->lda, g->ldw, g->ldc, device_cus(), &row0, &parts);
         if (parts != g->tail_parts || row0 != g->tail_row0 || !g->C_tail || ((uintptr_t)g->C_tail % 16)) {
             *err = "gemm: split-K tail does not match vv_gemm_tail_plan for this shape"; return -22;
         }

@@ -9,7 +9,7 @@
 typedef vv_gemm_args vvk_gemm_args;
 
 int vvk_gemm(const vv_gemm_args* g, hipStream_t st, const char** err);
-void vvk_gemm_tail_plan(int M, int N, int K, int* row0, int* parts);
+void vvk_gemm_tail_plan(int M, int N, int K, int lda, int ldw, int ldc, int* row0, int* parts);
 int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err);
 int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err);
 int vvk_posconv(const vv_posconv_args* a, hipStream_t st, const char** err);

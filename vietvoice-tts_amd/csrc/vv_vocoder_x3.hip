@@ -335,8 +335,11 @@ hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
     // 3 workgroups per CU (2 taps per phase, <= 168 VGPRs, taps not unrolled) where the kernel fits with at most a few spilled dwords:
     // k = 3, k = 7 and the transposed form are 4-11 % faster per launch; k = 11 keeps 2 workgroups per CU and 4 taps per phase (at 168
     // VGPRs it spills 21-65 dwords and is 10 % slower): profiles/r02/voc_x3_conv_shapes_occ3*.txt
-    if (a->wg_rows != 128 && (KW <= 7 || TR)) return launch_x3_t<KW, TR, 2, 2, 4, 3>(a, st);
-    if (a->rows_total <= 64 || a->wg_rows != 128) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4, 2>(a, st);
+    // the 128-row form loads weight rows up to n_rt * 128 - 1 of each [ko] slab: only when the padded slab has them (rows_pad is a
+    // multiple of 64, not necessarily of 128 -- e.g. 192 rows: the 64-row form is taken)
+    const bool wide = a->wg_rows == 128 && a->rows_pad % 128 == 0;
+    if (!wide && (KW <= 7 || TR)) return launch_x3_t<KW, TR, 2, 2, 4, 3>(a, st);
+    if (a->rows_total <= 64 || !wide) return launch_x3_t<KW, TR, 2, (4 < KW ? 4 : KW), 4, 2>(a, st);
     return launch_x3_t<KW, TR, 2, 2, 8, 2>(a, st);
 }
 

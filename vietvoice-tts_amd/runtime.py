@@ -406,7 +406,9 @@ class GraphedDecode:
     that lives as long as this object, so later calls that grow the context arena cannot invalidate the graph.
     ``__call__`` copies the state in and replays."""
 
-    def __init__(self, eng: HipSynth, B: int, N: int, t_gen_max: int):
+    def __init__(self, eng: HipSynth, B: int, N: int, t_gen_max: int, ws: Optional[torch.Tensor] = None):
+        """ws: optional caller-owned uint8 workspace of at least ``vv_decode_ws_bytes`` bytes (a ``DecodeGraphCache`` shares one
+        block between all graphs of an engine: replays are serialised by the engine lock on one stream)."""
         self.eng, self.B, self.N, self.t_gen_max = eng, B, N, t_gen_max
         dev, s = eng.device, eng.spec
         self.x = torch.zeros((B, N, s.n_mel), dtype=torch.float32, device=dev)
@@ -416,7 +418,10 @@ class GraphedDecode:
         self.pcm_len = torch.zeros((B,), dtype=torch.int32, device=dev)
         nb = C.c_uint64()
         eng._check(eng.lib.vv_decode_ws_bytes(eng.ctx, B, t_gen_max, C.byref(nb)))
-        self.ws = torch.empty((int(nb.value),), dtype=torch.uint8, device=dev)       # torch allocations are 512-byte aligned
+        if ws is not None:
+            assert ws.is_cuda and ws.dtype == torch.uint8 and ws.numel() >= int(nb.value)
+        self.ws = ws if ws is not None else torch.empty((int(nb.value),), dtype=torch.uint8, device=dev)   # torch allocations are 512-byte aligned
+        self.ws_need = int(nb.value)
         self._launch()                                   # warm-up: sets kernel attributes before capture
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -437,3 +442,69 @@ class GraphedDecode:
             self.seq_len.copy_(seq_len)
             self.graph.replay()
         return self.pcm, self.pcm_len
+
+
+    def io_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.x, self.ref_len, self.seq_len, self.pcm, self.pcm_len))
+
+
+class DecodeGraphCache:
+    """Bounded cache of captured decode graphs for one engine, keyed by (B, N, t_gen_max).
+
+    A service with varied voices sees a new generated-frame count per reference clip; unbounded, every key would pin its own
+    workspace (5 x B x max(C*T) x 4 B: ~170 MB per item at full size) for the life of the engine.  Here
+      * the workspace is ONE block shared by every graph of the cache (replays are serialised by the engine lock on one stream);
+        it is replaced by a larger one only when a new key needs more -- graphs captured on the old block keep it alive until
+        they are evicted;
+      * entries are evicted least-recently-used beyond ``max_entries`` or when the pinned bytes (distinct workspace blocks +
+        per-graph I/O buffers) exceed ``max_bytes``;
+      * callers bucket the key (``bucket``): N to multiples of 128 frames, t_gen_max to multiples of 64, so that nearby clips and
+        chunk lengths share a graph (the decode masks every item by its own lengths).
+    """
+
+    def __init__(self, eng: HipSynth, max_entries: int = 8, max_bytes: int = 16 << 30):
+        from collections import OrderedDict
+        self.eng, self.max_entries, self.max_bytes = eng, max(1, int(max_entries)), int(max_bytes)
+        self._graphs: "OrderedDict[Tuple[int, int, int], GraphedDecode]" = OrderedDict()
+        self._ws: Optional[torch.Tensor] = None
+        self.hits = self.misses = self.evictions = 0
+
+    @staticmethod
+    def bucket(N: int, t_gen: int) -> Tuple[int, int]:
+        Nb = (int(N) + 127) // 128 * 128
+        return Nb, min(Nb, (int(t_gen) + 63) // 64 * 64)
+
+    def pinned_bytes(self) -> int:
+        blocks = {g.ws.data_ptr(): g.ws.numel() for g in self._graphs.values()}
+        if self._ws is not None:
+            blocks[self._ws.data_ptr()] = self._ws.numel()
+        return sum(blocks.values()) + sum(g.io_bytes() for g in self._graphs.values())
+
+    def __len__(self):
+        return len(self._graphs)
+
+    def __contains__(self, key):
+        return key in self._graphs
+
+    def get(self, B: int, N: int, t_gen_max: int) -> GraphedDecode:
+        key = (int(B), int(N), int(t_gen_max))
+        g = self._graphs.get(key)
+        if g is not None:
+            self.hits += 1
+            self._graphs.move_to_end(key)
+            return g
+        self.misses += 1
+        nb = C.c_uint64()
+        self.eng._check(self.eng.lib.vv_decode_ws_bytes(self.eng.ctx, key[0], key[2], C.byref(nb)))
+        if self._ws is None or self._ws.numel() < int(nb.value):
+            self._ws = torch.empty((int(nb.value),), dtype=torch.uint8, device=self.eng.device)
+        g = GraphedDecode(self.eng, *key, ws=self._ws)
+        self._graphs[key] = g
+        while len(self._graphs) > 1 and (len(self._graphs) > self.max_entries or self.pinned_bytes() > self.max_bytes):
+            self._graphs.popitem(last=False)          # least recently used; its graph, I/O buffers (and old block) are released
+            self.evictions += 1
+        return g
+
+    def clear(self):
+        self._graphs.clear()
+        self._ws = None
