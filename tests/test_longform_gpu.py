@@ -6,8 +6,11 @@ from a captured hipGraph.  The text is bench.py's long-form text (4,096 characte
 Checked: the chunk count is the plan's; the buffered result (`synthesize`) with the captured vocoder equals the eager (no graph)
 engine on the same seed; `synthesize_stream` with the same 8-chunk groups equals the buffered result; the second call on one
 engine replays the cached graph (hit, no new capture).  bf16 acoustic: the chunks of one text are grouped by length in the
-buffered call and in text order in the streamed one, i.e. a chunk shares its GEMM launch with different neighbours -- rows are
-packed and every kernel is row- or sequence-local, so the results agree to the LSB bounds below (measured; printed).
+buffered call and in text order in the streamed one, i.e. a chunk shares its GEMM launches with different neighbours.  Rows are
+packed and every kernel is row- or sequence-local, so with the split-K tail of the FF2 GEMM off (the one place where a row's
+arithmetic depends on its position in the launch: tail rows sum four bf16-rounded K parts) streamed and buffered audio are equal
+to the cross-fade's LSB; with the default tail they agree in the bf16 tolerance class (measured 3.4e-4 rmse / rms, 24 LSB max on
+a +-20,000 LSB signal; bounds = 3 x).
 """
 import numpy as np
 import pytest
@@ -18,11 +21,14 @@ SENT = "Hôm nay trời đẹp quá, chúng ta cùng nhau đi dạo quanh hồ v
 TEXT = (SENT * 60)[:4096]
 
 
-def _engine(tmp, **kw):
+def _engine(tmp, split_k_tail=None, **kw):
     from vietvoice_tts_amd.core import ModelConfig, TTSEngine
     cfg = ModelConfig(model_cache_dir=str(tmp), synthetic_model=True, model_spec="full", acoustic_dtype="bf16", nfe_step=32,
                       max_batch_chunks=8, **kw)
-    return TTSEngine(cfg)
+    eng = TTSEngine(cfg)
+    if split_k_tail is not None:
+        eng.model_session_manager.engine.set_option("split_k_tail", split_k_tail)
+    return eng
 
 
 def _diff(a, b):
@@ -69,11 +75,16 @@ def test_longform_4k_chars_batch8_hipgraph_vocoder(tmp_path):
     e.cleanup()
     mx_e, share_e, rel_e = _diff(we, wg)
     print(f"[longform full bf16] hipGraph vocoder vs eager: max {mx_e} LSB, share beyond 1 LSB {share_e:.2e}, rmse/rms {rel_e:.2e}")
-    assert mx_e <= LSB_GRAPH_VS_EAGER and share_e <= 1e-4
-    assert mx <= LSB_STREAM_VS_BUFFERED and rel <= REL_STREAM_VS_BUFFERED
+    assert mx_e <= 1 and share_e <= 1e-4
+    assert mx <= 72 and rel <= 1e-3                     # default split-K tail: bf16 tolerance class, 3 x measured
 
-
-# bounds: see the module docstring; filled from the first measured run (round 3)
-LSB_GRAPH_VS_EAGER = 1
-LSB_STREAM_VS_BUFFERED = 2
-REL_STREAM_VS_BUFFERED = 1e-3
+    # ---- the same comparison with the position-dependent split-K tail off: every row's arithmetic is independent of its batch
+    b0 = _engine(tmp_path, split_k_tail=0, use_hip_graph=True)
+    w0, _ = b0.synthesize(TEXT)
+    b0.cleanup()
+    s0 = _engine(tmp_path, split_k_tail=0, use_hip_graph=True)
+    ws0 = np.concatenate(list(s0.synthesize_stream(TEXT, chunks_per_step=8)))
+    s0.cleanup()
+    mx0, share0, rel0 = _diff(ws0, w0)
+    print(f"[longform full bf16] split_k_tail = 0: streamed vs buffered max {mx0} LSB, share beyond 1 LSB {share0:.2e}, rmse/rms {rel0:.2e}")
+    assert mx0 <= 2 and share0 <= 1e-4

@@ -301,6 +301,37 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
 // the other group) before the reads of phase q+1.
 // =====================================================================================================
 #define VV_WAITVM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef VV_GEMM_STAMP
+// Diagnostic build ONLY (tools/gemm_stamp.py; never the shipped library): s_memtime stamps around the load segment, the barriers
+// and the MFMA cluster of every phase, and around the epilogue, summed per wave in scalar registers; lane 0 of waves 0 and 4 stores
+// the sums to the debug buffer handed in through vv_gemm_args.C_tail.  The stamps' own waits change the timing: read SHARES.
+#define VV_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VV_ST_DECL unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_t4 = 0
+#define VV_ST_ACC() do { st_sumL += st_t1 - st_t0; st_sumB += (st_t2 - st_t1) + (st_t4 - st_t3); st_sumC += st_t3 - st_t2; ++st_n; } while (0)
+#else
+#define VV_STAMP(v) do { } while (0)
+#define VV_ST_DECL do { } while (0)
+#define VV_ST_ACC() do { } while (0)
+#endif
+#ifdef VV_GEMM_M1
+// M1: ONE barrier per phase and wave.  Group 0 runs  L(q) | bar | C(q)  and goes straight on to L(q+1); group 1 runs  L(q)  C(q) | bar.
+// Between two barriers group 0 does [C(q), L(q+1)] and group 1 [L(q), C(q)]: each group's cluster still runs beside the other's
+// load segment, but the matrix pipe is handed from one group to the other WITHOUT a barrier in between (the ~65 cycles an interval
+// lost around its barriers are paid once per 32 MFMAs, not once per 16).  One barrier fewer lies between a wave's counted wait and
+// the other group's read of that data, so the wait retires everything staged >= 3 phases ago: vmcnt(6) (22 with the 16 stores).
+// In the first K-tile of a tile the previous tile's 16 output stores are still counted (they are OLDER than this K-tile's pieces
+// and younger than the previous tile's): phases 0-2 wait for pieces staged before those stores, so 16 more operations may stay
+// in flight (22); phase 3 waits for the pieces of THIS K-tile's phase 0, which were issued after the stores: plain 6.
+#define VV_PHASE_WAIT(relaxed) do { if constexpr (relaxed) VV_WAITVM(22); else VV_WAITVM(6); } while (0)
+#define VV_PHASE3_WAIT(relaxed) VV_WAITVM(6)
+#define VV_BAR_PRE() do { if (g == 0) bar(); } while (0)
+#define VV_BAR_POST() do { if (g == 1) bar(); } while (0)
+#else
+#define VV_PHASE_WAIT(relaxed) do { if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8); } while (0)
+#define VV_PHASE3_WAIT(relaxed) VV_PHASE_WAIT(relaxed)
+#define VV_BAR_PRE() bar()
+#define VV_BAR_POST() bar()
+#endif
 
 template <int MODE, typename To>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
@@ -330,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     const int n_my = n_my_main + (jb < n_tail ? (n_tail - jb + bpx - 1) / bpx : 0);
     if (n_my == 0) return;
     const int nk_full = K >> 6;                                // >= 2 per entry (host-checked)
-    auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) {
+    auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) __attribute__((always_inline)) {
         if (ks == 1 || i < n_my_main) {
             const int E = jb + i * bpx;
             bm_ = ((E / n_tiles) * 8 + x) * 256; bn_ = (E % n_tiles) * 256; part_ = 0; nk_ = nk_full;
@@ -353,13 +384,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     constexpr bool G1 = sizeof(To) == 2 && MODE != MODE_GATE_RES;
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
     const unsigned st_lane = ((unsigned)(lane >> 3) * (unsigned)ldc + (unsigned)(lane & 7) * 8u) * 2u;     // store: row lane>>3, 16-byte chunk lane&7
-    auto lane_get = [&](float v, int src_lane) {
+    auto lane_get = [&](float v, int src_lane) __attribute__((always_inline)) {
         return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
     };
     // a dword load hipcc does not count: no compiler-inserted vmcnt for it (that wait would drain the stores and the LDS-DMA
     // ring); its completion is covered by the explicit counted wait at the end of the epilogue, which also names the
     // destination so that nothing reads or copies it earlier (cdna guide 5.7 item 1, form ii)
-    auto load_async = [&](const float* p) {
+    auto load_async = [&](const float* p) __attribute__((always_inline)) {
         float v;
         asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
         return v;
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         for (int h = 0; h < 2; ++h) voff_a[h][u] = (unsigned)(loc_a[u] + h * 64) * (unsigned)lda * 2u + cbyte[u];
     }
     // stage unit `type` of K-tile Tk (parity par) of the tile whose origin is (bmS, bnS)
-    auto stage = [&](auto type_c, int bmS, int bnS, int Tk, int par) {
+    auto stage = [&](auto type_c, int bmS, int bnS, int Tk, int par) __attribute__((always_inline)) {
         constexpr int type = decltype(type_c)::value;
         constexpr int h = type >> 1;
         char* slot = smem + (par * 4 + type) * UNIT + wave * 2048;
@@ -409,19 +440,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     bf16x8 wfr[2][2][2];       // [n-half][ni][ks]
     bf16x8 afr[4][2];          // [mi][ks]   (one m-half at a time)
 
-    auto read_w = [&](int nh, const char* unit) {
+    auto read_w = [&](int nh, const char* unit) __attribute__((always_inline)) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) wfr[nh][ni][ks] = *(const bf16x8*)(unit + w_row0 + (ni << 11) + lane_off[ks]);
     };
-    auto read_a = [&](const char* unit) {
+    auto read_a = [&](const char* unit) __attribute__((always_inline)) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) afr[mi][ks] = *(const bf16x8*)(unit + a_row0 + (mi << 11) + lane_off[ks]);
     };
-    auto cluster = [&](int mh, int nh) {
+    auto cluster = [&](int mh, int nh, int ws) __attribute__((always_inline)) {       // quadrant (mh, nh); the n-half's W fragments are in register set ws
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -429,14 +460,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nh][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
+                    acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[ws][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto bar = [&]() {
+    auto bar = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+#ifdef VV_GEMM_STAMP
+    unsigned long long st_sumL = 0, st_sumB = 0, st_sumC = 0, st_sumE = 0, st_n = 0, st_start = 0, st_end = 0, st_e0 = 0, st_e1 = 0;
+    VV_ST_DECL;
+#endif
     int nk = nk_full;                                          // K-tiles of the CURRENT entry (the K-tile bodies read it by reference)
     // One K-tile = four phases.  The staging schedule is continuous across tiles: K-tile T of the current tile
     // stages Wn1/Am1 of K-tile T+1 and Wn0/Am0 of K-tile T+2, which roll over into the NEXT tile of this
@@ -444,11 +479,63 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // stages, so the counted wait is always vmcnt(8): everything staged more than four phases ago has landed.
     // The last tile of a block "prefetches" itself again (harmless: those slots are free), which keeps the
     // loop free of conditionals; the kernel drains with vmcnt(0) before it exits.
-    auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) {
+#ifdef VV_GEMM_BAL
+    // BAL: the LDS reads of a K-tile are spread 8 / 4 / 8 / 4 over its four load segments instead of 12 / 4 / 8 / 0: the next
+    // K-tile's Wn0 fragments are read in phase 3 (whose segment had no reads) into the W register set that died with phase 2's
+    // cluster, so the two sets swap roles every K-tile (XS = the set holding this K-tile's n-half 0).  The first K-tile of a tile
+    // reads its own Wn0 (nothing is held in registers across the epilogue), the last one prefetches nothing.
+    // Every entry has an even K-tile count, so K-tile T of a tile always sits in LDS parity T & 1 = XS: a compile-time constant (the
+    // fragment addresses of a body are one base register + immediates).
+    auto ktile = [&](auto relaxed_c, auto xs_c, auto first_c, auto last_c, int T, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
+        constexpr bool relaxed = decltype(relaxed_c)::value, first = decltype(first_c)::value, last = decltype(last_c)::value;
+        constexpr int XS = decltype(xs_c)::value, YS = 1 - XS, par = XS;
+        const char* base = smem + par * (4 * UNIT);
+        VV_STAMP(st_t0);
+        const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
+        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;      // absolute K-tile indices
+        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? kb_n + T + 2 - nk : kb_c + T + 2;
+        // ---- phase 0: quadrant (m0, n0)
+        if constexpr (first) read_w(XS, base + 0 * UNIT);
+        read_a(base + 1 * UNIT);
+        stage(T2{}, bm1, bn1, t1, par ^ 1);
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 0, XS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        // ---- phase 1: quadrant (m0, n1)
+        read_w(YS, base + 2 * UNIT);
+        stage(T3{}, bm1, bn1, t1, par ^ 1);
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 1, YS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        // ---- phase 2: quadrant (m1, n1)
+        read_a(base + 3 * UNIT);
+        stage(T0{}, bm2, bn2, t2, par);
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 1, YS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        // ---- phase 3: quadrant (m1, n0); set YS is free: Wn0 of the next K-tile (the other parity; staged 5 phases ago)
+        if constexpr (!last) read_w(YS, smem + (par ^ 1) * (4 * UNIT) + 0 * UNIT);
+        stage(T1{}, bm2, bn2, t2, par);
+        VV_PHASE3_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 0, XS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+    };
+    using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+    // the K-tiles of one tile: first (set 0), then pairs (set 1, set 0) -- an explicit unroll by two, so that the prefetched
+    // fragments live in ONE fixed register set at the loop head -- and the last (set 1) without the prefetch.  nk is even and >= 2
+    // (host-checked: K % 128 == 0, and an even K-tile count per split-K part).
+    auto ktiles = [&](auto relaxed_c, int& Gc, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
+        ktile(relaxed_c, B0{}, std::true_type{}, std::false_type{}, 0, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+        for (int T = 1; T + 1 < nk; T += 2) {
+            ktile(std::false_type{}, B1{}, std::false_type{}, std::false_type{}, T, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+            ktile(std::false_type{}, B0{}, std::false_type{}, std::false_type{}, T + 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+        }
+        ktile(std::false_type{}, B1{}, std::false_type{}, std::true_type{}, nk - 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+        Gc += nk;
+    };
+#else
+    auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
         // relaxed: the 16 epilogue stores of the previous tile are still counted by vmcnt (stores and loads retire in issue
         // order); everything this K-tile reads was staged BEFORE them, so the counted wait may leave them in flight too.
         constexpr bool relaxed = decltype(relaxed_c)::value;
         const char* base = smem + par * (4 * UNIT);
+        VV_STAMP(st_t0);
         const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
         const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;      // absolute K-tile indices
         const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? kb_n + T + 2 - nk : kb_c + T + 2;
@@ -456,24 +543,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         read_w(0, base + 0 * UNIT);
         read_a(base + 1 * UNIT);
         stage(T2{}, bm1, bn1, t1, par ^ 1);
-        if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8);
-        bar(); cluster(0, 0); bar();
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 0, 0); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 1: quadrant (m0, n1)
         read_w(1, base + 2 * UNIT);
         stage(T3{}, bm1, bn1, t1, par ^ 1);
-        if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8);
-        bar(); cluster(0, 1); bar();
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 1, 1); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 2: quadrant (m1, n1)
         read_a(base + 3 * UNIT);
         stage(T0{}, bm2, bn2, t2, par);
-        if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8);
-        bar(); cluster(1, 1); bar();
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 1, 1); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 3: quadrant (m1, n0)   (both W fragment sets are still in registers)
         stage(T1{}, bm2, bn2, t2, par);
-        if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8);
-        bar(); cluster(1, 0); bar();
+        VV_PHASE3_WAIT(relaxed);
+        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 0, 0); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
     };
 
+
+    auto ktiles = [&](auto relaxed_c, int& Gc, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
+        ktile(relaxed_c, 0, Gc & 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+        ++Gc;
+        for (int T = 1; T < nk; ++T, ++Gc) ktile(std::false_type{}, T, Gc & 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
+    };
+#endif
 
     // prologue = phases -6..-1 of the staging schedule for this block's first tile
     {
@@ -501,6 +595,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 
     int G = 0;                                                 // global K-tile counter (LDS parity)
     bool stores_pending = false;
+#ifdef VV_GEMM_STAMP
+    VV_STAMP(st_start);
+#endif
     for (int it = 0; it < n_my; ++it) {
         int bm, bn, part, bm_n, bn_n, part_n, nk_n;
         entry(it, bm, bn, part, nk);
@@ -539,15 +636,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
         if constexpr (G1) {
-            ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);             // 16 stores (real or dropped) always precede a tile
+            ktiles(std::true_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);                   // 16 stores (real or dropped) always precede a tile
         } else if constexpr (MODE == MODE_STORE) {
-            if (stores_pending) ktile(std::true_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
-            else ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
+            if (stores_pending) ktiles(std::true_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);
+            else ktiles(std::false_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);
         } else {
-            ktile(std::false_type{}, 0, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
+            ktiles(std::false_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);
         }
-        ++G;
-        for (int T = 1; T < nk; ++T, ++G) ktile(std::false_type{}, T, G & 1, bm, bn, bm_n, bn_n, kb, kb_n);
         stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && bm + 256 <= M && bn + 256 <= e.n_store;
 
         // E2: both groups run their epilogue in the SAME barrier interval.  With the plain one-segment stagger, group 0's epilogue
@@ -556,7 +651,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (group 1 is in its last cluster), and group 1 re-establishes the stagger with one barrier after its epilogue.
         // (Letting group 0 run its pre-pass and first store pass inside that interval instead of idling was measured: QKV +1.4 %,
         // the rest flat -- profiles/r02/gemm_notes.md.)
+#ifndef VV_GEMM_M1
         if (g == 0) bar();
+#endif
+#ifdef VV_GEMM_STAMP
+        VV_STAMP(st_e0);
+#endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
             // x * sigmoid(2u) == 0.5 x (1 + tanh u);  sigmoid(w) = 1 / (1 + 2^(-w log2 e)): the -log2(e) is folded into the constants
@@ -727,8 +827,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         }
                 }
         }
+#ifdef VV_GEMM_STAMP
+        VV_STAMP(st_e1);
+        st_sumE += st_e1 - st_e0;
+#endif
+#ifndef VV_GEMM_M1
         if (g == 1) bar();                                     // group 1 falls one segment behind again
+#endif
     }
+#ifdef VV_GEMM_STAMP
+    VV_STAMP(st_end);
+    if (lane == 0 && wc == 0 && e.c_part) {
+        unsigned long long* d = (unsigned long long*)e.c_part + ((size_t)blockIdx.x * 2 + g) * 8;
+        d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my;
+    }
+#endif
     if (g == 0) bar();                                         // balance group 1's extra barrier
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
 }
@@ -869,6 +982,9 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
     e.seq_rcp = (unsigned)((((unsigned long long)1 << 32) + (unsigned)e.seq_n - 1) / (unsigned)e.seq_n);
     e.ks = 1; e.c_part = nullptr; e.tail_panel0 = 0;
+#ifdef VV_GEMM_STAMP
+    if (!g->tail_parts) e.c_part = (char*)g->C_tail;           // diagnostic build: the debug buffer of the stamps
+#endif
     if (g->tail_parts) {
         int row0 = 0, parts = 0;
         if (g->mode == MODE_GATE_STORE && g->dtype == VV_BF16 && g->out_dtype == VV_BF16 && (g->tile == 0 || g->tile == 256))

@@ -366,77 +366,84 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
     }
 }
 
-// ---- K13: conv_post (C -> 1, k = KW) on lrelu(x), tanh, *32767, clip, truncate to int16.  HBM-bound:
-// 4*C bytes read + 2 written per sample.  The window [t0-4, t0+TP+4) of 8 channels is staged with ALIGNED
-// 16-byte loads (the conv's -3 offset would otherwise force 4-byte loads), activation applied once per element.
-template <int KW>
+// ---- K13: conv_post (C -> 1, k = 7) on lrelu(x), tanh, *32767, clip, truncate to int16.  HBM-bound: 4*C bytes read + 2 written
+// per sample, and the kernel is written as a STREAM: no LDS, no barrier.  A lane owns 4 consecutive output samples and loads
+// exactly its own aligned float4 of every channel (one coalesced 1 KiB load per wave and channel, 8 channels = 8 loads in
+// flight per lane before the first use); the 3 + 3 halo samples of the k = 7 window come from the neighbouring lanes by DPP
+// whole-wave shifts (wave_shr:1 / wave_shl:1), so lanes 0 and 63 of a wave are halo lanes that only load -- a wave produces
+// 62 x 4 = 248 samples and the waves of a row overlap by two float4 (3 % of the bytes, served by L2).  Weights are wave-uniform
+// scalar loads.  The FMA order (channel-major, taps 0..6) is the one of the round-1 LDS-window kernel: PCM is bit-identical.
+// (That kernel staged 8 channels x 1,032 samples through LDS with two barriers per pass: one pass of loads in flight per
+// workgroup, 0.34-0.40 ms at the headline batch = 0.34-0.41 of HBM; profiles/r03/vocoder_notes.md.)
+__device__ __forceinline__ float wave_prev(float v) {      // lane i <- lane i - 1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_next(float v) {      // lane i <- lane i + 1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+constexpr int POST_WAVE_OUT = 62 * 4;       // samples produced per wave
+// VEC: rows are 16-byte aligned (T % 4 == 0): one buffer_load_dwordx4 per lane and channel; otherwise four dword loads.  Loads go
+// through a buffer resource of the row's VALID bytes (len_in samples): the left halo of a row's first wave (negative offset) and
+// everything past the valid length read as zero from the hardware range check -- the main path has no branch and no exec mask.
+template <int KW, bool VEC, int CB /* channels loaded ahead of their use; divides C */>
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ in, const float* __restrict__ w /*[C][KW]*/,
                                                         float bias, int16_t* __restrict__ pcm, int ld_pcm, float* __restrict__ wave_f32,
                                                         int C, int T, float pre_slope, const int* __restrict__ len_in) {
-    constexpr int TP = 1024;                 // outputs per block (4 per thread)
-    constexpr int CH = 8;
-    constexpr int XW4 = TP / 4 + 2;          // float4 per channel row: covers t0-4 .. t0+TP+3
-    constexpr int XWP = XW4 * 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = (float*)smem;                // [CH][XWP]
-    float* wsm = xs + CH * XWP;              // [C][KW] (C <= 64)
+    static_assert(KW == 7, "the window is 3 + 4 + 3 samples");
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * TP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = (blockIdx.x * 4 + wave) * POST_WAVE_OUT + (lane - 1) * 4;       // first of this lane's 4 samples (lane 0: the left halo)
     const int lin = len_in ? min(len_in[b], T) : T;
-    const float* inb = in + (size_t)b * C * T;
-    const bool vec_ok = (T & 3) == 0;        // rows stay 16-byte aligned
-    for (int i = threadIdx.x; i < C * KW; i += 256) wsm[i] = w[i];
+    const float* row = in + (size_t)b * C * T;
+    // a float4 that straddles the valid length is cut per element (the range check of a 16-byte load is not relied on for that)
+    const bool m1 = t + 1 < lin, m2 = t + 2 < lin, m3 = t + 3 < lin;
     float acc[4] = {bias, bias, bias, bias};
-    const int tl = threadIdx.x * 4;
-    for (int c0 = 0; c0 < C; c0 += CH) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < CH * XW4; i += 256) {
-            const int c = i / XW4, k4 = i - c * XW4;
-            const int pos = t0 - 4 + k4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + c < C) {
-                const float* row = inb + (size_t)(c0 + c) * T;
-                if (vec_ok && pos >= 0 && pos + 3 < lin) {
-                    v = *(const float4*)(row + pos);
-                } else {
-                    if (pos + 0 >= 0 && pos + 0 < lin) v.x = row[pos + 0];
-                    if (pos + 1 >= 0 && pos + 1 < lin) v.y = row[pos + 1];
-                    if (pos + 2 >= 0 && pos + 2 < lin) v.z = row[pos + 2];
-                    if (pos + 3 >= 0 && pos + 3 < lin) v.w = row[pos + 3];
-                }
-            }
-            *(float4*)(xs + c * XWP + k4 * 4) = make_float4(lrelu(v.x, pre_slope), lrelu(v.y, pre_slope), lrelu(v.z, pre_slope), lrelu(v.w, pre_slope));
-        }
-        __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += CB) {         // CB = 8: 8 KiB in flight per wave
+        float4 v[CB];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (c0 + c >= C) break;
-            // outputs tl..tl+3 need window indices (tl + 4 - KW/2) .. (tl + 4 + 3 + KW/2): three aligned float4
-            const float4 a0 = *(const float4*)(xs + c * XWP + tl), a1 = *(const float4*)(xs + c * XWP + tl + 4),
-                         a2 = *(const float4*)(xs + c * XWP + tl + 8);
-            const float xv[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        for (int c = 0; c < CB; ++c) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(row + (size_t)(c0 + c) * T), 0, lin * 4, 0x00020000);
+            if constexpr (VEC) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 4, 0, 2);      // nt: read once
+                v[c].x = __uint_as_float(q[0]);                                    // t >= lin: the whole load is out of range (zeros)
+                v[c].y = m1 ? __uint_as_float(q[1]) : 0.f;
+                v[c].z = m2 ? __uint_as_float(q[2]) : 0.f;
+                v[c].w = m3 ? __uint_as_float(q[3]) : 0.f;
+            } else {
+                v[c].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t * 4, 0, 2));
+                v[c].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t * 4 + 4, 0, 2));
+                v[c].z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t * 4 + 8, 0, 2));
+                v[c].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t * 4 + 12, 0, 2));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const float x4 = lrelu(v[c].x, pre_slope), x5 = lrelu(v[c].y, pre_slope), x6 = lrelu(v[c].z, pre_slope), x7 = lrelu(v[c].w, pre_slope);
+            // window xv[1..10] = samples t - 3 .. t + 6 (xv[o + k + 1] multiplies tap k of output o, as in the LDS-window kernel)
+            const float xv[12] = {0.f, wave_prev(x5), wave_prev(x6), wave_prev(x7), x4, x5, x6, x7, wave_next(x4), wave_next(x5), wave_next(x6), 0.f};
+            const float* wc = w + (c0 + c) * KW;              // wave-uniform: scalar loads
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const float wk = wsm[(c0 + c) * KW + k];
+                const float wk = wc[k];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, xv[o + k + 4 - KW / 2], acc[o]);
             }
         }
     }
-    short4 pk;
-    float4 wf;
+    if (lane == 0 || lane == 63 || t >= T) return;          // halo lanes, and lanes past the row
     float ys[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) ys[o] = tanhf(acc[o]);
-    wf = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    short4 pk;
     pk.x = (short)fminf(fmaxf(ys[0] * 32767.0f, -32768.0f), 32767.0f);     // truncation toward zero, as an ONNX Cast does
     pk.y = (short)fminf(fmaxf(ys[1] * 32767.0f, -32768.0f), 32767.0f);
     pk.z = (short)fminf(fmaxf(ys[2] * 32767.0f, -32768.0f), 32767.0f);
     pk.w = (short)fminf(fmaxf(ys[3] * 32767.0f, -32768.0f), 32767.0f);
-    const int t = t0 + tl;
-    if (t + 3 < T && (ld_pcm & 3) == 0 && vec_ok) {
+    if (VEC && t + 3 < T && (ld_pcm & 3) == 0) {
         *(short4*)(pcm + (size_t)b * ld_pcm + t) = pk;
-        if (wave_f32) *(float4*)(wave_f32 + (size_t)b * T + t) = wf;
+        if (wave_f32) *(float4*)(wave_f32 + (size_t)b * T + t) = make_float4(ys[0], ys[1], ys[2], ys[3]);
     } else {
         const short ps[4] = {pk.x, pk.y, pk.z, pk.w};
         for (int o = 0; o < 4 && t + o < T; ++o) {
@@ -559,9 +566,15 @@ int vvk_conv_post(const float* in, const float* w, float bias, int16_t* pcm, int
                   float pre_slope, const int* len_in, hipStream_t st, const char** err) {
     if (KW != 7 || C > 64 || C < 1) { *err = "conv_post: k=7 and C<=64 expected"; return -22; }
     if (!(pre_slope > 0.f && pre_slope <= 1.f)) { *err = "conv_post: pre_slope must be in (0, 1]"; return -22; }
-    const size_t lds = (size_t)(8 * (1024 + 8) + C * 7) * sizeof(float);
-    dim3 grid((T + 1023) / 1024, B);
-    conv_post_kernel<7><<<grid, 256, lds, st>>>(in, w, bias, pcm, ld_pcm, wave_f32, C, T, pre_slope, len_in);
+    dim3 grid((T + 4 * POST_WAVE_OUT - 1) / (4 * POST_WAVE_OUT), B);          // 4 waves x 248 samples per workgroup
+    if ((size_t)T * 4 >= ((size_t)1 << 31)) { *err = "conv_post: rows of 2 GiB or more"; return -22; }
+    const bool vec = (T & 3) == 0 && ((uintptr_t)in % 16) == 0;
+#define POST_GO(VEC, CB) conv_post_kernel<7, VEC, CB><<<grid, 256, 0, st>>>(in, w, bias, pcm, ld_pcm, wave_f32, C, T, pre_slope, len_in)
+    if (vec && C % 8 == 0) POST_GO(true, 8);
+    else if (vec && C % 4 == 0) POST_GO(true, 4);
+    else if (vec) POST_GO(true, 1);
+    else POST_GO(false, 1);
+#undef POST_GO
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) { *err = hipGetErrorString(he); return -5; }
     return 0;
