@@ -56,6 +56,27 @@ for name, mode, N, K, act in shapes:
         outs.append(out); args.append(a)
     torch.cuda.synchronize()
     diffs = [float((o.float() - outs[0].float()).abs().max()) for o in outs[1:]]
+    if os.environ.get("GEMM_AB_REF"):          # ground truth on the first and the last 4096 rows (torch fp32 on the device)
+        errs = []
+        for o in outs:
+            e_max = 0.0
+            for lo in (0, M - 4096):
+                ref = A[lo:lo + 4096].float() @ W.float().t() + bias
+                if act == 1:
+                    ref = torch.nn.functional.gelu(ref, approximate="tanh")
+                if mode == 3:
+                    ref = ref * gate
+                if mode == 1 and not name.endswith("_off_probe"):
+                    p_ = pos[lo:lo + 4096].long()
+                    t = cs[p_]                                   # [rows][64] = (cos, sin) pairs of the compact table
+                    for part in (0, 1):                          # q and k columns
+                        x = ref[:, part * 1024:(part + 1) * 1024].reshape(4096, 16, 32, 2)
+                        c, sn = t[:, 0::2].reshape(4096, 1, 32), t[:, 1::2].reshape(4096, 1, 32)
+                        y = torch.stack((x[..., 0] * c - x[..., 1] * sn, x[..., 1] * c + x[..., 0] * sn), dim=-1)
+                        ref[:, part * 1024:(part + 1) * 1024] = y.reshape(4096, 1024)
+                e_max = max(e_max, float((o[lo:lo + 4096].float() - ref).abs().max()))
+            errs.append(round(e_max, 4))
+        print(f"{name:15s} max |err| vs torch fp32 on 8192 rows: {errs}", flush=True)
     times = [[] for _ in libs]
     for r in range(rounds):
         for i, (e, a) in enumerate(zip(engs, args)):

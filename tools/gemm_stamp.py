@@ -47,6 +47,8 @@ for p in libs:
             v = d[:, grp]
             n, tiles, tot = v[:, 4].mean(), v[:, 6].mean(), v[:, 5].mean()
             L, B, Cc, E = v[:, 0].sum() / v[:, 4].sum(), v[:, 1].sum() / v[:, 4].sum(), v[:, 2].sum() / v[:, 4].sum(), v[:, 3].sum() / v[:, 6].sum()
-            print(f"{name:15s} group {grp}: per phase L {L:6.0f}  barriers {B:6.0f}  cluster {Cc:6.0f}  (sum {L + B + Cc:6.0f}) | epilogue per tile {E:7.0f} | "
+            SW = v[:, 7].long()
+            S, Wt = (SW & 0xffffffff).double().sum() / v[:, 6].sum(), (SW >> 32).double().sum() / v[:, 6].sum()
+            print(f"{name:15s} group {grp}: per tile set-up {S:6.0f}  wait before the epilogue {Wt:6.0f} | per phase L {L:6.0f}  barriers {B:6.0f}  cluster {Cc:6.0f}  (sum {L + B + Cc:6.0f}) | epilogue per tile {E:7.0f} | "
                   f"kernel {tot:9.0f} cycles, {tiles:.2f} tiles/block, phases {n:.0f}: loop {100 * (v[:, 0] + v[:, 1] + v[:, 2]).mean() / tot:4.1f} %  epilogue {100 * v[:, 3].mean() / tot:4.1f} %", flush=True)
     e.close()

@@ -113,6 +113,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
     constexpr int MW = CFG == 1 ? 128 : 64;        // tokens per wave
     constexpr int NWAVE = CFG == 2 ? 16 : (CFG == 1 ? 8 : 4);
     constexpr int PPW = BT / 8 / NWAVE;            // LDS-DMA pieces per wave per tile
+    // (a four-stage ring with counted waits, one workgroup per CU, was measured SLOWER for the single-utterance shapes than this
+    // two-stage loop at two workgroups per CU: 97.9 against 94.1 ms of GEMM per utterance, profiles/r03/gemm_notes.md)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | W tile)
 
     const int id = blockIdx.x;
@@ -152,6 +154,12 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
 
     const int nk = K / BK;
     stage(0, 0);
+    auto ring_step = [&](int kt) __attribute__((always_inline)) {       // top of K-tile kt: its pieces have landed, the other stage is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    };
+    constexpr int NST = 2;
 
     if constexpr (sizeof(T) == 2) {
         // ------------------------------------------------ bf16: 4 x (MW/16) tiles of 16x16x32
@@ -163,10 +171,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-            const char* sa = smem + (kt & 1) * STAGE_BYTES;
+            ring_step(kt);
+            const char* sa = smem + (kt % NST) * STAGE_BYTES;
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -221,10 +227,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int r32 = lane & 31, h = lane >> 5;
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-            const char* sa = smem + (kt & 1) * STAGE_BYTES;
+            ring_step(kt);
+            const char* sa = smem + (kt % NST) * STAGE_BYTES;
             const char* sw = sa + TILE_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -313,25 +317,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
 #define VV_ST_DECL do { } while (0)
 #define VV_ST_ACC() do { } while (0)
 #endif
-#ifdef VV_GEMM_M1
-// M1: ONE barrier per phase and wave.  Group 0 runs  L(q) | bar | C(q)  and goes straight on to L(q+1); group 1 runs  L(q)  C(q) | bar.
-// Between two barriers group 0 does [C(q), L(q+1)] and group 1 [L(q), C(q)]: each group's cluster still runs beside the other's
-// load segment, but the matrix pipe is handed from one group to the other WITHOUT a barrier in between (the ~65 cycles an interval
-// lost around its barriers are paid once per 32 MFMAs, not once per 16).  One barrier fewer lies between a wave's counted wait and
-// the other group's read of that data, so the wait retires everything staged >= 3 phases ago: vmcnt(6) (22 with the 16 stores).
-// In the first K-tile of a tile the previous tile's 16 output stores are still counted (they are OLDER than this K-tile's pieces
-// and younger than the previous tile's): phases 0-2 wait for pieces staged before those stores, so 16 more operations may stay
-// in flight (22); phase 3 waits for the pieces of THIS K-tile's phase 0, which were issued after the stores: plain 6.
-#define VV_PHASE_WAIT(relaxed) do { if constexpr (relaxed) VV_WAITVM(22); else VV_WAITVM(6); } while (0)
-#define VV_PHASE3_WAIT(relaxed) VV_WAITVM(6)
-#define VV_BAR_PRE() do { if (g == 0) bar(); } while (0)
-#define VV_BAR_POST() do { if (g == 1) bar(); } while (0)
-#else
 #define VV_PHASE_WAIT(relaxed) do { if constexpr (relaxed) VV_WAITVM(24); else VV_WAITVM(8); } while (0)
-#define VV_PHASE3_WAIT(relaxed) VV_PHASE_WAIT(relaxed)
-#define VV_BAR_PRE() bar()
-#define VV_BAR_POST() bar()
-#endif
+#define VV_CLUSTER(mh, nh, ws) do { cluster(mh, nh, ws); VV_STAMP(st_t3); bar(); } while (0)
 
 template <int MODE, typename To>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
@@ -360,6 +347,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     const int n_my_main = jb < n_main ? (n_main - jb + bpx - 1) / bpx : 0;
     const int n_my = n_my_main + (jb < n_tail ? (n_tail - jb + bpx - 1) / bpx : 0);
     if (n_my == 0) return;
+#ifdef VV_GEMM_STAGGER
+    // STAGGER experiment: all workgroups start together and their tiles take the same time, so the 256 CUs reach their epilogues in
+    // lock-step and 32 MB of output leave the chip in one burst per round.  Workgroups that have one tile fewer than the longest walk
+    // (the tile count is rarely a multiple of the CU count) start late by a hashed fraction of a tile time -- they finish no later than
+    // the others, and the epilogue bursts of the launch are spread out.
+    {
+        const int n_max = (n_main + bpx - 1) / bpx + (n_tail + bpx - 1) / bpx;
+        if (n_my < n_max) {
+            const unsigned frac = ((unsigned)blockIdx.x * 2654435761u) >> 24;          // 0..255
+            const unsigned long long wait = (unsigned long long)(K >> 6) * VV_GEMM_STAGGER * frac / 256;      // cycles
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     const int nk_full = K >> 6;                                // >= 2 per entry (host-checked)
     auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) __attribute__((always_inline)) {
         if (ks == 1 || i < n_my_main) {
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     };
 #ifdef VV_GEMM_STAMP
     unsigned long long st_sumL = 0, st_sumB = 0, st_sumC = 0, st_sumE = 0, st_n = 0, st_start = 0, st_end = 0, st_e0 = 0, st_e1 = 0;
+    unsigned long long st_sumS = 0, st_sumW = 0, st_s0 = 0, st_s1 = 0, st_w0 = 0;      // tile set-up (entry, bias into the accumulators), wait in front of the epilogue
     VV_ST_DECL;
 #endif
     int nk = nk_full;                                          // K-tiles of the CURRENT entry (the K-tile bodies read it by reference)
@@ -479,57 +482,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // stages, so the counted wait is always vmcnt(8): everything staged more than four phases ago has landed.
     // The last tile of a block "prefetches" itself again (harmless: those slots are free), which keeps the
     // loop free of conditionals; the kernel drains with vmcnt(0) before it exits.
-#ifdef VV_GEMM_BAL
-    // BAL: the LDS reads of a K-tile are spread 8 / 4 / 8 / 4 over its four load segments instead of 12 / 4 / 8 / 0: the next
-    // K-tile's Wn0 fragments are read in phase 3 (whose segment had no reads) into the W register set that died with phase 2's
-    // cluster, so the two sets swap roles every K-tile (XS = the set holding this K-tile's n-half 0).  The first K-tile of a tile
-    // reads its own Wn0 (nothing is held in registers across the epilogue), the last one prefetches nothing.
-    // Every entry has an even K-tile count, so K-tile T of a tile always sits in LDS parity T & 1 = XS: a compile-time constant (the
-    // fragment addresses of a body are one base register + immediates).
-    auto ktile = [&](auto relaxed_c, auto xs_c, auto first_c, auto last_c, int T, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
-        constexpr bool relaxed = decltype(relaxed_c)::value, first = decltype(first_c)::value, last = decltype(last_c)::value;
-        constexpr int XS = decltype(xs_c)::value, YS = 1 - XS, par = XS;
-        const char* base = smem + par * (4 * UNIT);
-        VV_STAMP(st_t0);
-        const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
-        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;      // absolute K-tile indices
-        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? kb_n + T + 2 - nk : kb_c + T + 2;
-        // ---- phase 0: quadrant (m0, n0)
-        if constexpr (first) read_w(XS, base + 0 * UNIT);
-        read_a(base + 1 * UNIT);
-        stage(T2{}, bm1, bn1, t1, par ^ 1);
-        VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 0, XS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
-        // ---- phase 1: quadrant (m0, n1)
-        read_w(YS, base + 2 * UNIT);
-        stage(T3{}, bm1, bn1, t1, par ^ 1);
-        VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 1, YS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
-        // ---- phase 2: quadrant (m1, n1)
-        read_a(base + 3 * UNIT);
-        stage(T0{}, bm2, bn2, t2, par);
-        VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 1, YS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
-        // ---- phase 3: quadrant (m1, n0); set YS is free: Wn0 of the next K-tile (the other parity; staged 5 phases ago)
-        if constexpr (!last) read_w(YS, smem + (par ^ 1) * (4 * UNIT) + 0 * UNIT);
-        stage(T1{}, bm2, bn2, t2, par);
-        VV_PHASE3_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 0, XS); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
-    };
-    using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
-    // the K-tiles of one tile: first (set 0), then pairs (set 1, set 0) -- an explicit unroll by two, so that the prefetched
-    // fragments live in ONE fixed register set at the loop head -- and the last (set 1) without the prefetch.  nk is even and >= 2
-    // (host-checked: K % 128 == 0, and an even K-tile count per split-K part).
-    auto ktiles = [&](auto relaxed_c, int& Gc, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
-        ktile(relaxed_c, B0{}, std::true_type{}, std::false_type{}, 0, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
-        for (int T = 1; T + 1 < nk; T += 2) {
-            ktile(std::false_type{}, B1{}, std::false_type{}, std::false_type{}, T, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
-            ktile(std::false_type{}, B0{}, std::false_type{}, std::false_type{}, T + 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
-        }
-        ktile(std::false_type{}, B1{}, std::false_type{}, std::true_type{}, nk - 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
-        Gc += nk;
-    };
-#else
     auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
         // relaxed: the 16 epilogue stores of the previous tile are still counted by vmcnt (stores and loads retire in issue
         // order); everything this K-tile reads was staged BEFORE them, so the counted wait may leave them in flight too.
@@ -544,21 +496,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         read_a(base + 1 * UNIT);
         stage(T2{}, bm1, bn1, t1, par ^ 1);
         VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 0, 0); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        VV_STAMP(st_t1); bar(); VV_STAMP(st_t2); VV_CLUSTER(0, 0, 0); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 1: quadrant (m0, n1)
         read_w(1, base + 2 * UNIT);
         stage(T3{}, bm1, bn1, t1, par ^ 1);
         VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(0, 1, 1); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        VV_STAMP(st_t1); bar(); VV_STAMP(st_t2); VV_CLUSTER(0, 1, 1); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 2: quadrant (m1, n1)
         read_a(base + 3 * UNIT);
         stage(T0{}, bm2, bn2, t2, par);
         VV_PHASE_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 1, 1); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        VV_STAMP(st_t1); bar(); VV_STAMP(st_t2); VV_CLUSTER(1, 1, 1); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
         // ---- phase 3: quadrant (m1, n0)   (both W fragment sets are still in registers)
         stage(T1{}, bm2, bn2, t2, par);
-        VV_PHASE3_WAIT(relaxed);
-        VV_STAMP(st_t1); VV_BAR_PRE(); VV_STAMP(st_t2); cluster(1, 0, 0); VV_STAMP(st_t3); VV_BAR_POST(); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
+        VV_PHASE_WAIT(relaxed);
+        VV_STAMP(st_t1); bar(); VV_STAMP(st_t2); VV_CLUSTER(1, 0, 0); VV_STAMP(st_t4); VV_ST_ACC(); VV_STAMP(st_t0);
     };
 
 
@@ -567,7 +519,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         ++Gc;
         for (int T = 1; T < nk; ++T, ++Gc) ktile(std::false_type{}, T, Gc & 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
     };
-#endif
 
     // prologue = phases -6..-1 of the staging schedule for this block's first tile
     {
@@ -599,6 +550,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     VV_STAMP(st_start);
 #endif
     for (int it = 0; it < n_my; ++it) {
+#ifdef VV_GEMM_STAMP
+        VV_STAMP(st_s0);
+#endif
         int bm, bn, part, bm_n, bn_n, part_n, nk_n;
         entry(it, bm, bn, part, nk);
         const bool last = it + 1 == n_my;
@@ -635,6 +589,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // first K-tile after a full bf16 tile store (every wave issued exactly 16 stores): leave those stores in flight
         // (compiled for the plain / activation store mode only: in the rope and gate modes the second K-tile body costs
         // registers -- 20 spilled VGPRs in the rope epilogue -- and measured neutral to -8 %; FF1 gains 7 %)
+#ifdef VV_GEMM_STAMP
+        VV_STAMP(st_s1);
+        st_sumS += st_s1 - st_s0;
+#endif
         if constexpr (G1) {
             ktiles(std::true_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);                   // 16 stores (real or dropped) always precede a tile
         } else if constexpr (MODE == MODE_STORE) {
@@ -643,6 +601,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         } else {
             ktiles(std::false_type{}, G, bm, bn, bm_n, bn_n, kb, kb_n);
         }
+#ifdef VV_GEMM_STAMP
+        VV_STAMP(st_w0);
+#endif
         stores_pending = sizeof(To) == 2 && MODE != MODE_GATE_RES && bm + 256 <= M && bn + 256 <= e.n_store;
 
         // E2: both groups run their epilogue in the SAME barrier interval.  With the plain one-segment stagger, group 0's epilogue
@@ -651,11 +612,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (group 1 is in its last cluster), and group 1 re-establishes the stagger with one barrier after its epilogue.
         // (Letting group 0 run its pre-pass and first store pass inside that interval instead of idling was measured: QKV +1.4 %,
         // the rest flat -- profiles/r02/gemm_notes.md.)
-#ifndef VV_GEMM_M1
         if (g == 0) bar();
-#endif
 #ifdef VV_GEMM_STAMP
         VV_STAMP(st_e0);
+        st_sumW += st_e0 - st_w0;
 #endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
@@ -831,15 +791,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         VV_STAMP(st_e1);
         st_sumE += st_e1 - st_e0;
 #endif
-#ifndef VV_GEMM_M1
         if (g == 1) bar();                                     // group 1 falls one segment behind again
-#endif
     }
 #ifdef VV_GEMM_STAMP
     VV_STAMP(st_end);
     if (lane == 0 && wc == 0 && e.c_part) {
         unsigned long long* d = (unsigned long long*)e.c_part + ((size_t)blockIdx.x * 2 + g) * 8;
-        d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my;
+        d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my; d[7] = st_sumS + (st_sumW << 32);
     }
 #endif
     if (g == 0) bar();                                         // balance group 1's extra barrier
