@@ -347,21 +347,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     const int n_my_main = jb < n_main ? (n_main - jb + bpx - 1) / bpx : 0;
     const int n_my = n_my_main + (jb < n_tail ? (n_tail - jb + bpx - 1) / bpx : 0);
     if (n_my == 0) return;
-#ifdef VV_GEMM_STAGGER
-    // STAGGER experiment: all workgroups start together and their tiles take the same time, so the 256 CUs reach their epilogues in
-    // lock-step and 32 MB of output leave the chip in one burst per round.  Workgroups that have one tile fewer than the longest walk
-    // (the tile count is rarely a multiple of the CU count) start late by a hashed fraction of a tile time -- they finish no later than
-    // the others, and the epilogue bursts of the launch are spread out.
-    {
-        const int n_max = (n_main + bpx - 1) / bpx + (n_tail + bpx - 1) / bpx;
-        if (n_my < n_max) {
-            const unsigned frac = ((unsigned)blockIdx.x * 2654435761u) >> 24;          // 0..255
-            const unsigned long long wait = (unsigned long long)(K >> 6) * VV_GEMM_STAGGER * frac / 256;      // cycles
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-#endif
     const int nk_full = K >> 6;                                // >= 2 per entry (host-checked)
     auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) __attribute__((always_inline)) {
         if (ks == 1 || i < n_my_main) {
