@@ -130,5 +130,80 @@ def test_bf16_production_run_close_to_the_oracle_fixture(gold):
     assert wr <= 2.0 * BF16_MEASURED["wave"], wr
 
 
+def test_bf16_headline_batch_item0_production_run(gold):
+    """configs[2] itself: the headline batch (B = 32, bench inputs, bf16 acoustic + fp32-fidelity vocoder, the split-K tail on) through
+    `synthesize_batch` -- the call bench.py times -- with the production step count; item 0 of the batch against the oracle fixture
+    (same bounds as the single-utterance run: rows are packed and every kernel is row- or sequence-local), the whole batch finite,
+    full length and not one utterance repeated."""
+    import bench
+    from vietvoice_tts_amd.runtime import HipSynth
+    g = gold
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in g["d"].items()}
+    eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
+    x, pcm, pcm_len, _pre = eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], g["N"], d["noise"], bench.GEN_FRAMES,
+                                                 seq_len_host=d["seq_len_host"])
+    torch.cuda.synchronize()
+    eng.close()
+    n = g["arr"]["pcm"].size
+    assert bool((pcm_len == n).all()) and bool(torch.isfinite(x).all())
+    ref = torch.from_numpy(g["arr"]["x31"]).double()
+    got = x[0].cpu().double()
+    rm = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    ref_pcm = torch.from_numpy(g["arr"]["pcm"]).double()
+    pr = float((pcm[0, :n].cpu().double() - ref_pcm).pow(2).mean().sqrt() / ref_pcm.pow(2).mean().sqrt())
+    print(f"\n[full bf16 B=32, 31 steps] item 0 vs the float64 fixture: state rmse/rms {rm:.3e}, PCM rmse/rms {pr:.3e}")
+    assert rm <= 2.0 * BF16_MEASURED[31] and pr <= 2.0 * BF16_MEASURED["wave"]
+    assert float((x[1] - x[0]).abs().max()) > 1e-2 and float(pcm.float().abs().amax(dim=1).min()) > 0
+
+
+def test_fp32_ragged_batch_production_run():
+    """BASELINE configs[3] semantics with the production step count at FULL size: three utterances of different reference-clip, text
+    and frame lengths as ONE packed ragged batch (per-item masks in attention / pos-conv / text conv, packed GEMM rows, bucketed
+    vocoder), fp32, all 31 steps; items 1 and 2 against the float64 oracle run on each item ALONE
+    (tests/golden/fullsize_ragged_golden.*, generator `make_fullsize_golden.py --ragged`), bounds from the torch-fp32 yardstick."""
+    import importlib.util
+    import bench  # noqa: F401  (the generator module imports it)
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec_ = importlib.util.spec_from_file_location("vv_make_fullsize_golden", os.path.join(GOLD, "make_fullsize_golden.py"))
+    gen = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(gen)
+    with open(os.path.join(GOLD, "fullsize_ragged_golden.json")) as fh:
+        meta = json.load(fh)
+    arr = np.load(os.path.join(GOLD, "fullsize_ragged_golden.npz"))
+    spec = ModelSpec.full()
+    w = make_synthetic_weights(spec, bench.SEED)
+    audio, ids, seq, noise = gen.ragged_inputs(spec)
+    assert seq == meta["seq"] and _digest(audio) == meta["inputs"]["audio"] and _digest(ids) == meta["inputs"]["ids"] and _digest(noise) == meta["inputs"]["noise"]
+    la, lt, gf = meta["la"], meta["lt"], meta["gf"]
+    N = max(seq)
+    eng = HipSynth(spec, w, acoustic_dtype="fp32", nfe_step=32)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    pre = eng.preprocess(audio.to(DEV), i32(la), ids.to(DEV), i32(lt), i32(seq), N, seq_len_host=seq)
+    x = noise.to(DEV).clone()
+    eng.transformer_steps(x, pre, 0, 31)
+    pcm, pcm_len = eng.decode_bucketed(x, pre, gf, pad_frac=0.10, min_units=1)
+    torch.cuda.synchronize()
+    eng.close()
+    checks = []
+    for b in (1, 2):
+        it = meta["items"][str(b)]
+        y = it["torch_fp32_vs_f64"]
+        ref = torch.from_numpy(arr[f"x31_{b}"]).double()
+        got = x[b, : seq[b]].cpu().double()
+        err = (got - ref).abs()
+        mx, rm = float(err.max()), float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        n = arr[f"pcm_{b}"].size
+        dp = (pcm[b, :n].cpu().int() - torch.from_numpy(arr[f"pcm_{b}"]).int()).abs()
+        print(f"\n[full fp32 ragged, 31 steps] item {b} (N = {seq[b]}, T = {lt[b]}, gen = {gf[b]}): HIP max|err| {mx:.2e} rmse/rms {rm:.2e} | torch-fp32 oracle "
+              f"{y['max_err']:.2e} / {y['rmse_over_rms']:.2e}; PCM max diff {int(dp.max())} LSB ({int((dp > 0).sum())} of {n} differ; torch-fp32 {y['pcm_max_lsb']} LSB)")
+        assert int(pre["ref_signal_len"][b]) == it["ref_signal_len"] and int(pcm_len[b]) == n == gf[b] * spec.hop_length
+        # measured: item 1 max err 2.9e-3 (2.8 x the torch-fp32 figure, one element of a state of range 12.8) / rmse 1.25 x; item 2 1.07 x / 0.81 x
+        checks += [(f"state max err item {b}", mx, 4.0 * y["max_err"] + 2e-6), (f"state rmse item {b}", rm, 2.0 * y["rmse_over_rms"] + 2e-7),
+                   (f"pcm lsb item {b}", int(dp.max()), y["pcm_max_lsb"] + 1), (f"pcm share beyond 1 LSB item {b}", float((dp > 1).float().mean()), 1e-4)]
+    bad = [c for c in checks if not c[1] <= c[2]]
+    assert not bad, bad
+
+
 # state rmse/rms after steps 1, 8, 16, 24, 31 and waveform rmse/rms of the bf16 run above, as first measured (round 3)
 BF16_MEASURED = {1: 1.83e-5, 8: 9.02e-4, 16: 2.91e-3, 24: 4.49e-3, 31: 5.17e-3, "wave": 5.06e-3}
