@@ -30,7 +30,7 @@ for p in libs:
         bias = (torch.randn(N, generator=g) * 0.1).to(dev)
         gate = torch.randn(N, generator=g).to(dev)
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
-        dbg = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(256 * 2 * 10, dtype=torch.int64, device=dev)
         a = rt.vv_gemm_args()
         a.dtype, a.out_dtype, a.mode, a.act = rt.VV_BF16, rt.VV_BF16, mode, act
         a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K
@@ -42,13 +42,14 @@ for p in libs:
         for _ in range(20):
             assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
         torch.cuda.synchronize()
-        d = dbg.view(256, 2, 8).cpu().double()
+        d = dbg.view(256, 2, 10).cpu().double()
         for grp in (0, 1):
             v = d[:, grp]
             n, tiles, tot = v[:, 4].mean(), v[:, 6].mean(), v[:, 5].mean()
             L, B, Cc, E = v[:, 0].sum() / v[:, 4].sum(), v[:, 1].sum() / v[:, 4].sum(), v[:, 2].sum() / v[:, 4].sum(), v[:, 3].sum() / v[:, 6].sum()
             SW = v[:, 7].long()
             S, Wt = (SW & 0xffffffff).double().sum() / v[:, 6].sum(), (SW >> 32).double().sum() / v[:, 6].sum()
-            print(f"{name:15s} group {grp}: per tile set-up {S:6.0f}  wait before the epilogue {Wt:6.0f} | per phase L {L:6.0f}  barriers {B:6.0f}  cluster {Cc:6.0f}  (sum {L + B + Cc:6.0f}) | epilogue per tile {E:7.0f} | "
+            clk = float((v[:, 5] / v[:, 8].clamp(min=1)).median()) * 0.1
+            print(f"{name:15s} group {grp}: clock {clk:.2f} GHz (s_memtime / s_memrealtime) | per tile set-up {S:6.0f}  wait before the epilogue {Wt:6.0f} | per phase L {L:6.0f}  barriers {B:6.0f}  cluster {Cc:6.0f}  (sum {L + B + Cc:6.0f}) | epilogue per tile {E:7.0f} | "
                   f"kernel {tot:9.0f} cycles, {tiles:.2f} tiles/block, phases {n:.0f}: loop {100 * (v[:, 0] + v[:, 1] + v[:, 2]).mean() / tot:4.1f} %  epilogue {100 * v[:, 3].mean() / tot:4.1f} %", flush=True)
     e.close()

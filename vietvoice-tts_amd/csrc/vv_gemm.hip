@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     };
 #ifdef VV_GEMM_STAMP
     unsigned long long st_sumL = 0, st_sumB = 0, st_sumC = 0, st_sumE = 0, st_n = 0, st_start = 0, st_end = 0, st_e0 = 0, st_e1 = 0;
-    unsigned long long st_sumS = 0, st_sumW = 0, st_s0 = 0, st_s1 = 0, st_w0 = 0;      // tile set-up (entry, bias into the accumulators), wait in front of the epilogue
+    unsigned long long st_sumS = 0, st_sumW = 0, st_s0 = 0, st_s1 = 0, st_w0 = 0, st_rt0 = 0;      // tile set-up (entry, bias into the accumulators), wait in front of the epilogue
     VV_ST_DECL;
 #endif
     int nk = nk_full;                                          // K-tiles of the CURRENT entry (the K-tile bodies read it by reference)
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     bool stores_pending = false;
 #ifdef VV_GEMM_STAMP
     VV_STAMP(st_start);
+    st_rt0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz: cycles / realtime ticks x 100 MHz = the clock this kernel ran at
 #endif
     for (int it = 0; it < n_my; ++it) {
 #ifdef VV_GEMM_STAMP
@@ -781,8 +782,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #ifdef VV_GEMM_STAMP
     VV_STAMP(st_end);
     if (lane == 0 && wc == 0 && e.c_part) {
-        unsigned long long* d = (unsigned long long*)e.c_part + ((size_t)blockIdx.x * 2 + g) * 8;
-        d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my; d[7] = st_sumS + (st_sumW << 32);
+        unsigned long long* d = (unsigned long long*)e.c_part + ((size_t)blockIdx.x * 2 + g) * 10;
+        d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my; d[7] = st_sumS + (st_sumW << 32); d[8] = __builtin_amdgcn_s_memrealtime() - st_rt0;
     }
 #endif
     if (g == 0) bar();                                         // balance group 1's extra barrier
