@@ -385,3 +385,87 @@ def test_decode_graph_cache_buckets():
     # nearby reference clips (5.90 s .. 6.10 s) share one key
     keys = {DecodeGraphCache.bucket(1664, 1664 - (int(s * 24000) // 256 + 1)) for s in (5.9, 5.95, 6.0, 6.05, 6.1)}
     assert len(keys) == 1
+
+
+def test_decode_graph_cache_lru_and_shared_workspace(monkeypatch):
+    """The bounded cache of captured decode graphs, without a GPU: GraphedDecode is replaced by a stub that records what
+    it was given.  Least-recently-used eviction beyond max_entries, ONE workspace block shared by the graphs (replaced only by a
+    larger one), hits / misses / evictions counted, the byte budget enforced."""
+    import ctypes as C
+    import types
+    from vietvoice_tts_amd import runtime as rt
+
+    class FakeTensor:
+        def __init__(self, n, ptr):
+            self._n, self._p = n, ptr
+
+        def numel(self):
+            return self._n
+
+        def element_size(self):
+            return 1
+
+        def data_ptr(self):
+            return self._p
+
+    made = []
+
+    class StubGraph:
+        def __init__(self, eng, B, N, t, ws=None):
+            self.key, self.ws = (B, N, t), ws
+            made.append(self.key)
+
+        def io_bytes(self):
+            return 1000
+
+    need = {}
+
+    def ws_bytes(ctx, B, t, out):
+        out._obj.value = need.get((B, t), 100 * B * t)
+        return 0
+    eng = types.SimpleNamespace(lib=types.SimpleNamespace(vv_decode_ws_bytes=ws_bytes), ctx=None, device="cpu", _check=lambda rc: None)
+    ptrs = iter(range(1, 100))
+    monkeypatch.setattr(rt, "GraphedDecode", StubGraph)
+    monkeypatch.setattr(rt.torch, "empty", lambda shape, dtype=None, device=None: FakeTensor(shape[0], next(ptrs)))
+    c = rt.DecodeGraphCache(eng, max_entries=2, max_bytes=10 ** 9)
+    a = c.get(1, 128, 64)
+    assert c.get(1, 128, 64) is a and (c.hits, c.misses) == (1, 1)
+    b = c.get(1, 256, 64)                       # same workspace need: shares the block
+    assert b.ws is a.ws and len(c) == 2
+    big = c.get(2, 256, 128)                    # needs more: a new block; the least recently used graph (a) is evicted
+    assert big.ws is not a.ws and len(c) == 2 and (1, 128, 64) not in c and c.evictions == 1
+    assert c.get(1, 256, 64) is b               # still cached, now most recent
+    c.get(1, 128, 64)                           # re-captured (miss) on the CURRENT (larger) block; evicts `big`
+    assert made.count((1, 128, 64)) == 2 and (2, 256, 128) not in c and c.evictions == 2
+    assert {g.ws.data_ptr() for g in c._graphs.values()} <= {a.ws.data_ptr(), big.ws.data_ptr()}
+    # byte budget: a budget below two graphs' pinned bytes keeps one entry
+    tight = rt.DecodeGraphCache(eng, max_entries=8, max_bytes=100 * 1 * 64 + 1500)
+    tight.get(1, 128, 64); tight.get(1, 256, 64)
+    assert len(tight) == 1 and tight.evictions == 1
+
+
+def test_fullsize_fixture_inputs_are_reproducible_here():
+    """The production-run fixtures store no inputs: the -m gpu tests regenerate them from seeds and compare digests.  The same check on
+    the CPU for the cheap part (clips, ids, noise of both fixtures), so generator drift shows up without a GPU."""
+    import hashlib
+    import importlib.util
+    import json
+    import torch
+    import bench
+    from vietvoice_tts_amd.model_spec import ModelSpec
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    dg = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()[:16]
+    spec = ModelSpec.full()
+    with open(os.path.join(gold, "fullsize_golden.json")) as fh:
+        meta = json.load(fh)
+    g = torch.Generator().manual_seed(bench.SEED)              # item 0 of bench.make_inputs(spec, 32, 0, ...): the first draws of its stream
+    ids = torch.randint(1, spec.vocab_size, (32, bench.TEXT_TOKENS), generator=g, dtype=torch.int32)
+    noise = torch.randn(32, 1600, spec.n_mel, generator=g, dtype=torch.float32)
+    assert dg(bench.synth_reference_clip(0)) == meta["inputs"]["audio0"] and dg(ids[0]) == meta["inputs"]["ids0"] and dg(noise[0]) == meta["inputs"]["noise0"]
+    s_ = importlib.util.spec_from_file_location("vv_make_fullsize_golden", os.path.join(gold, "make_fullsize_golden.py"))
+    gen = importlib.util.module_from_spec(s_)
+    s_.loader.exec_module(gen)
+    with open(os.path.join(gold, "fullsize_ragged_golden.json")) as fh:
+        rmeta = json.load(fh)
+    audio, rids, seq, rnoise = gen.ragged_inputs(spec)
+    assert seq == rmeta["seq"] and dg(audio) == rmeta["inputs"]["audio"] and dg(rids) == rmeta["inputs"]["ids"] and dg(rnoise) == rmeta["inputs"]["noise"]
