@@ -20,7 +20,7 @@ for p in libs:
     rt._lib = None
     rt._lib = rt.load_library(p)
     engs.append(rt.HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4))
-M = 102400
+M = int(os.environ.get("GEMM_AB_M", 102400))          # 3200 = one utterance (1,600 frames x 2 CFG branches)
 g = torch.Generator().manual_seed(0)
 shapes = [("qkv_rope", 1, 3072, 1024, 0), ("qkv_rope_rows", 1, 3072, 1024, 0), ("out_gate_store", 3, 1024, 1024, 0), ("ff1_gelu", 0, 2048, 1024, 1), ("ff2_gate_store", 3, 1024, 2048, 0),
           # epilogue-cost probes (only with GEMM_AB_SHAPES): the QKV / FF1 shapes with the plain store epilogue
@@ -31,6 +31,7 @@ pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
 cs_rows = cs[pos.long()].contiguous()            # what vv_rope_rows builds once per call
 st = torch.cuda.current_stream().cuda_stream
 tot = {p: 0.0 for p in libs}
+tiles = [int(x) for x in os.environ.get("GEMM_AB_TILES", "").split(",") if x]      # per library: vv_gemm_args.tile (0 auto, 128, 256), e.g. one library twice as 0,128
 only = [x for x in os.environ.get("GEMM_AB_SHAPES", "").split(",") if x]      # e.g. the four shapes of one DiT block for a PMC pass
 for name, mode, N, K, act in shapes:
     if (only and name not in only) or (not only and (name.endswith("_plain_store") or name.endswith("_probe"))):
@@ -40,12 +41,14 @@ for name, mode, N, K, act in shapes:
     bias = (torch.randn(N, generator=g) * 0.1).to(dev)
     gate = torch.randn(N, generator=g).to(dev)
     outs, args = [], []
-    for e in engs:
+    for li, e in enumerate(engs):
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         a = rt.vv_gemm_args()
         a.dtype, a.out_dtype, a.mode, a.act = rt.VV_BF16, rt.VV_BF16, mode, act
         a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K
         a.bias, a.gate = bias.data_ptr(), (gate.data_ptr() if mode == 3 else None)
+        if tiles:
+            a.tile = tiles[li]
         if mode == 1:
             a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, (0 if name.endswith("_off_probe") else 1024)
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr(); a.rope_pos = pos.data_ptr()
@@ -60,21 +63,22 @@ for name, mode, N, K, act in shapes:
         errs = []
         for o in outs:
             e_max = 0.0
-            for lo in (0, M - 4096):
-                ref = A[lo:lo + 4096].float() @ W.float().t() + bias
+            for lo in sorted({0, max(M - 4096, 0)}):
+                R_ = min(4096, M - lo)
+                ref = A[lo:lo + R_].float() @ W.float().t() + bias
                 if act == 1:
                     ref = torch.nn.functional.gelu(ref, approximate="tanh")
                 if mode == 3:
                     ref = ref * gate
                 if mode == 1 and not name.endswith("_off_probe"):
-                    p_ = pos[lo:lo + 4096].long()
+                    p_ = pos[lo:lo + R_].long()
                     t = cs[p_]                                   # [rows][64] = (cos, sin) pairs of the compact table
                     for part in (0, 1):                          # q and k columns
-                        x = ref[:, part * 1024:(part + 1) * 1024].reshape(4096, 16, 32, 2)
-                        c, sn = t[:, 0::2].reshape(4096, 1, 32), t[:, 1::2].reshape(4096, 1, 32)
+                        x = ref[:, part * 1024:(part + 1) * 1024].reshape(R_, 16, 32, 2)
+                        c, sn = t[:, 0::2].reshape(R_, 1, 32), t[:, 1::2].reshape(R_, 1, 32)
                         y = torch.stack((x[..., 0] * c - x[..., 1] * sn, x[..., 1] * c + x[..., 0] * sn), dim=-1)
-                        ref[:, part * 1024:(part + 1) * 1024] = y.reshape(4096, 1024)
-                e_max = max(e_max, float((o[lo:lo + 4096].float() - ref).abs().max()))
+                        ref[:, part * 1024:(part + 1) * 1024] = y.reshape(R_, 1024)
+                e_max = max(e_max, float((o[lo:lo + R_].float() - ref).abs().max()))
             errs.append(round(e_max, 4))
         print(f"{name:15s} max |err| vs torch fp32 on 8192 rows: {errs}", flush=True)
     times = [[] for _ in libs]
@@ -91,6 +95,6 @@ for name, mode, N, K, act in shapes:
         t = sorted(times[i]); med = t[len(t) // 2]
         if name != "qkv_rope":
             tot[p] += med
-        line += f"  {os.path.basename(p)[9:-3]} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
+        line += f"  {os.path.basename(p)[9:-3]}{('/t%d' % tiles[i]) if tiles else ''} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
     print(line + f"  | max diff vs first {diffs}", flush=True)
 print("sum of qkv_rope_rows + out + ff1 + ff2 (one DiT block): " + "  ".join(f"{os.path.basename(p)[9:-3]} {tot[p]*1e3:.1f} us" for p in libs), flush=True)
