@@ -854,16 +854,16 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + OFF_A + h * 8192 + wc * 2048 + u * 1024), 16, (int)va[h][u], Tk * 128, 0, 0);
     };
 
-    auto stage_part = [&](auto q_c, int Tk, char* sb) __attribute__((always_inline)) {          // pieces 3q .. 3q+2 of the wave's 12
+    auto stage_part = [&](auto q_c, int Tk, char* sb, bool live = true) __attribute__((always_inline)) {          // pieces 3q .. 3q+2 of the wave's 12
         constexpr int q = decltype(q_c)::value;
 #pragma unroll
         for (int i = 3 * q; i < 3 * q + 3; ++i) {
             if (i < 8) {
                 const int h = i >> 2, j = i & 3;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sb + h * 16384 + wc * 4096 + j * 1024), 16, (int)vw[h][j], w_soff + Tk * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(live ? sb + h * 16384 + wc * 4096 + j * 1024 : smem + 3 * STAGE + wc * 1024), 16, (int)(live ? vw[h][j] : 0x7ffffff0u), w_soff + Tk * 128, 0, 0);
             } else {
                 const int h = (i - 8) >> 1, u = (i - 8) & 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + OFF_A + h * 8192 + wc * 2048 + u * 1024), 16, (int)va[h][u], Tk * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(live ? sb + OFF_A + h * 8192 + wc * 2048 + u * 1024 : smem + 3 * STAGE + wc * 1024), 16, (int)(live ? va[h][u] : 0x7ffffff0u), Tk * 128, 0, 0);
             }
         }
     };
@@ -909,6 +909,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
         for (int i = 0; i < 8; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             if (i < n_reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#ifdef SW_SPREAD2
+            if (i == 1 || i == 3 || i == 5) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#endif
         }
     };
     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
@@ -939,8 +942,14 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
         // ---- phase 0: quadrant (m0, n0); Wn1 of this K-tile is read beside it
         __builtin_amdgcn_sched_barrier(0);
 #ifdef SW_SPREAD
+#ifdef SW_SPREAD2
+        stage_part(std::integral_constant<int, 2>{}, T + 2, sb_prev, T >= 1 && T + 2 < nk);
+#else
         if (T >= 1 && T + 2 < nk) stage_part(std::integral_constant<int, 2>{}, T + 2, sb_prev);
+#endif
+#ifndef SW_SPREAD2
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
         read_w(p_c, 1, sb);
         cluster(p_c, 0, 0);
@@ -948,8 +957,14 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: (m0, n1); Am1 read beside it
 #ifdef SW_SPREAD
+#ifdef SW_SPREAD2
+        stage_part(std::integral_constant<int, 3>{}, T + 2, sb_prev, T >= 1 && T + 2 < nk);
+#else
         if (T >= 1 && T + 2 < nk) stage_part(std::integral_constant<int, 3>{}, T + 2, sb_prev);
+#endif
+#ifndef SW_SPREAD2
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
         read_a(p_c, 1, sb);
         cluster(p_c, 0, 1);
@@ -957,7 +972,11 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 2: every LDS read of this K-tile has been issued; once they are back (all waves: the barrier) its stage is free
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SW_SPREAD2
+        VV_WAITVM(12);
+#else
         if (T + 2 < nk) VV_WAITVM(12); else VV_WAITVM(0);              // this wave's pieces of K-tile T+1 have landed
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -965,18 +984,30 @@ __global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict_
 #ifndef SW_SPREAD
         if (T + 3 < nk) stage(T + 3, sb);
 #else
+#ifdef SW_SPREAD2
+        stage_part(std::integral_constant<int, 0>{}, T + 3, sb, T + 3 < nk);
+#else
         if (T + 3 < nk) stage_part(std::integral_constant<int, 0>{}, T + 3, sb);
 #endif
 #endif
+#endif
+#ifndef SW_SPREAD2
         __builtin_amdgcn_sched_barrier(0);
+#endif
         read_a(Q{}, 0, sb_next);                                       // (past the last K-tile: stale LDS, never used)
         cluster(p_c, 1, 1);
         spread(8);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 3: (m1, n0); next K-tile's Wn0 read beside it
 #ifdef SW_SPREAD
+#ifdef SW_SPREAD2
+        stage_part(std::integral_constant<int, 1>{}, T + 3, sb, T + 3 < nk);
+#else
         if (T + 3 < nk) stage_part(std::integral_constant<int, 1>{}, T + 3, sb);
+#endif
+#ifndef SW_SPREAD2
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
         read_w(Q{}, 0, sb_next);
         cluster(p_c, 1, 0);
@@ -1198,7 +1229,7 @@ inline bool sw_fits(int M, int N, int K, int lda, int ldw, int ldc, int act) {
 
 template <int MODE>
 hipError_t launch_sw(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
-    constexpr int LDS = 3 * 48 * 1024;
+    constexpr int LDS = 3 * 48 * 1024 + 4096;          // + a dump region for range-checked-away pieces (diagnostic variants)
     static KernelSetup setup;
     auto kern = gemm_sw_kernel<MODE>;
     if (hipError_t he = setup.ensure((const void*)kern, LDS, nullptr); he != hipSuccess) return he;
