@@ -790,356 +790,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
 }
 
-// =====================================================================================================
-// bf16 single-utterance kernel (M < 4096: one utterance is 2 x 1,600 rows): 128(m) x 256(n) tile, BK = 64, 4 waves = ONE per SIMD.
-//
-// At M = 3,200 the 128 x 128 kernel above runs at a third of a CU's matrix rate (0.66 us per K-tile with one workgroup on a CU and
-// the same per-CU rate with two: per K-tile it needs 512 cycles of the matrix pipe, 512 of LDS reads and 512 of the 64 B/clk
-// vector-memory path, none of them overlapped by a two-stage vmcnt(0) + __syncthreads() loop), and the 256 x 256 ping-pong kernel
-// has 100 - 156 tiles for 256 CUs.  Here wave wc owns all 128 tokens x features wc*64..+63 -- the ping-pong kernel's wave tile,
-// 24 fragment reads for 64 MFMAs per K-tile -- and, alone on its SIMD with 512 registers, pipelines in software what that kernel
-// gets from its second wave group: the K-tile is the same four quadrant phases (m0,n0) (m0,n1) (m1,n1) (m1,n0), and every phase
-// issues the LDS reads of the NEXT phase's new operand half into the other register set before its 16 MFMAs (K-tile parities
-// alternate register sets: the loop is unrolled by two).  LDS = 3 stages x 48 KiB (Wn0 | Wn1 | Am0 | Am1, cut by consumption
-// order as above; a wave stages its own 64 weight rows and a quarter of the tokens: 12 LDS-DMA pieces per K-tile), ONE barrier per
-// K-tile in front of phase 2 -- by then every read of the K-tile has completed, so its stage is refilled with K-tile T+3 right
-// behind the barrier and the counted wait for K-tile T+1 is vmcnt(12).  Epilogues as in the ping-pong kernel (bias in the
-// accumulators, LDS-transposed 128-byte row stores through the then idle ring).
-// =====================================================================================================
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void gemm_sw_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
-                                                         bf16* __restrict__ C, int ldc, int M, int N, int K, EpiArgs e, int m_tiles, int n_tiles) {
-    constexpr int STAGE = 48 * 1024, OFF_A = 32 * 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [stage 3][Wn0 16K | Wn1 16K | Am0 8K | Am1 8K]
-    const int lane = threadIdx.x & 63;
-    const int wc = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r16 = lane & 15, cq = lane >> 4;
-    const int xcd = blockIdx.x & 7, L = blockIdx.x >> 3;
-    const int mt = (L / n_tiles) * 8 + xcd, nt = L % n_tiles;      // an XCD owns whole token panels (as gemm_kernel)
-    if (mt >= m_tiles) return;
-    const int bm = mt * 128, bn = nt * 256;
-    const int nk = K >> 6;                                         // even and >= 4 (host-checked)
-
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)min((size_t)M * lda * 2, (size_t)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)min((size_t)N * ldw * 2, (size_t)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)min((size_t)M * ldc * 2, (size_t)0x7fffffff), 0x00020000);
-
-    // ---- LDS-DMA: per-lane byte offsets of this wave's 8 weight pieces and 4 token pieces of a stage (piece = 8 rows x 128 B; the
-    // XOR swizzle is applied on the source side).  Token rows past M are past num_records: the DMA writes zeros there.
-    unsigned vw[2][4], va[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ur = wc * 32 + j * 8 + (lane >> 3);
-            vw[h][j] = (unsigned)(wc * 64 + h * 32 + j * 8 + (lane >> 3)) * (unsigned)ldw * 2u + (unsigned)(((lane & 7) ^ ((ur >> 1) & 7)) * 16);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ur = wc * 16 + u * 8 + (lane >> 3);
-            va[h][u] = (unsigned)(bm + h * 64 + ur) * (unsigned)lda * 2u + (unsigned)(((lane & 7) ^ ((ur >> 1) & 7)) * 16);
-        }
-    }
-    const int w_soff = bn * ldw * 2;
-    auto stage = [&](int Tk, char* sb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sb + h * 16384 + wc * 4096 + j * 1024), 16, (int)vw[h][j], w_soff + Tk * 128, 0, 0);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + OFF_A + h * 8192 + wc * 2048 + u * 1024), 16, (int)va[h][u], Tk * 128, 0, 0);
-    };
-
-    auto stage_part = [&](auto q_c, int Tk, char* sb, bool live = true) __attribute__((always_inline)) {          // pieces 3q .. 3q+2 of the wave's 12
-        constexpr int q = decltype(q_c)::value;
-#pragma unroll
-        for (int i = 3 * q; i < 3 * q + 3; ++i) {
-            if (i < 8) {
-                const int h = i >> 2, j = i & 3;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(live ? sb + h * 16384 + wc * 4096 + j * 1024 : smem + 3 * STAGE + wc * 1024), 16, (int)(live ? vw[h][j] : 0x7ffffff0u), w_soff + Tk * 128, 0, 0);
-            } else {
-                const int h = (i - 8) >> 1, u = (i - 8) & 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(live ? sb + OFF_A + h * 8192 + wc * 2048 + u * 1024 : smem + 3 * STAGE + wc * 1024), 16, (int)(live ? va[h][u] : 0x7ffffff0u), Tk * 128, 0, 0);
-            }
-        }
-    };
-    unsigned lane_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) lane_off[ks] = (unsigned)((r16 << 7) | (((ks * 4 + cq) ^ ((r16 >> 1) & 7)) << 4));
-    const unsigned w_row0 = (unsigned)(wc * 32) << 7;
-
-    f32x4 acc[2][2][4][2];     // [m-half][n-half][mi][ni]
-    bf16x8 wf[2][2][2][2];     // [K-tile parity][n-half][ni][ks]
-    bf16x8 af[2][2][4][2];     // [K-tile parity][m-half][mi][ks]
-    auto read_w = [&](auto p_c, int nh, const char* sb) __attribute__((always_inline)) {
-        constexpr int p = decltype(p_c)::value;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[p][nh][ni][ks] = *(const bf16x8*)(sb + nh * 16384 + w_row0 + (ni << 11) + lane_off[ks]);
-    };
-    auto read_a = [&](auto p_c, int mh, const char* sb) __attribute__((always_inline)) {
-        constexpr int p = decltype(p_c)::value;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[p][mh][mi][ks] = *(const bf16x8*)(sb + OFF_A + mh * 8192 + (mi << 11) + lane_off[ks]);
-    };
-    auto cluster = [&](auto p_c, int mh, int nh) __attribute__((always_inline)) {
-        constexpr int p = decltype(p_c)::value;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#ifdef SW_NOMFMA
-                    { const bf16x8 w_ = wf[p][nh][ni][ks], a_ = af[p][mh][mi][ks]; asm volatile("" :: "v"(w_), "v"(a_)); }
-#else
-                    acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[p][nh][ni][ks], af[p][mh][mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
-#endif
-    };
-    // reads issued in front of a cluster are spread over it: one ds_read behind every second MFMA
-    auto spread = [&](int n_reads) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            if (i < n_reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#ifdef SW_SPREAD2
-            if (i == 1 || i == 3 || i == 5) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-#endif
-        }
-    };
-    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-
-    // accumulators start at the bias
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mh][nh][mi][ni] = b4;
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    stage(0, smem); stage(1, smem + STAGE); stage(2, smem + 2 * STAGE);
-    VV_WAITVM(24);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_w(P0{}, 0, smem); read_a(P0{}, 0, smem);
-
-    auto ktile = [&](auto p_c, int T, char* sb, const char* sb_next, char* sb_prev) __attribute__((always_inline)) {
-        constexpr int p = decltype(p_c)::value;
-        using Q = std::integral_constant<int, p ^ 1>;
-        // ---- phase 0: quadrant (m0, n0); Wn1 of this K-tile is read beside it
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef SW_SPREAD
-#ifdef SW_SPREAD2
-        stage_part(std::integral_constant<int, 2>{}, T + 2, sb_prev, T >= 1 && T + 2 < nk);
-#else
-        if (T >= 1 && T + 2 < nk) stage_part(std::integral_constant<int, 2>{}, T + 2, sb_prev);
-#endif
-#ifndef SW_SPREAD2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-        read_w(p_c, 1, sb);
-        cluster(p_c, 0, 0);
-        spread(4);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 1: (m0, n1); Am1 read beside it
-#ifdef SW_SPREAD
-#ifdef SW_SPREAD2
-        stage_part(std::integral_constant<int, 3>{}, T + 2, sb_prev, T >= 1 && T + 2 < nk);
-#else
-        if (T >= 1 && T + 2 < nk) stage_part(std::integral_constant<int, 3>{}, T + 2, sb_prev);
-#endif
-#ifndef SW_SPREAD2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-        read_a(p_c, 1, sb);
-        cluster(p_c, 0, 1);
-        spread(8);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 2: every LDS read of this K-tile has been issued; once they are back (all waves: the barrier) its stage is free
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef SW_SPREAD2
-        VV_WAITVM(12);
-#else
-        if (T + 2 < nk) VV_WAITVM(12); else VV_WAITVM(0);              // this wave's pieces of K-tile T+1 have landed
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#ifndef SW_NODMA
-#ifndef SW_SPREAD
-        if (T + 3 < nk) stage(T + 3, sb);
-#else
-#ifdef SW_SPREAD2
-        stage_part(std::integral_constant<int, 0>{}, T + 3, sb, T + 3 < nk);
-#else
-        if (T + 3 < nk) stage_part(std::integral_constant<int, 0>{}, T + 3, sb);
-#endif
-#endif
-#endif
-#ifndef SW_SPREAD2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        read_a(Q{}, 0, sb_next);                                       // (past the last K-tile: stale LDS, never used)
-        cluster(p_c, 1, 1);
-        spread(8);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 3: (m1, n0); next K-tile's Wn0 read beside it
-#ifdef SW_SPREAD
-#ifdef SW_SPREAD2
-        stage_part(std::integral_constant<int, 1>{}, T + 3, sb, T + 3 < nk);
-#else
-        if (T + 3 < nk) stage_part(std::integral_constant<int, 1>{}, T + 3, sb);
-#endif
-#ifndef SW_SPREAD2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-        read_w(Q{}, 0, sb_next);
-        cluster(p_c, 1, 0);
-        spread(4);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    {
-        int s0 = 0;
-        for (int T = 0; T < nk; T += 2) {
-            const int s1 = s0 == 2 * STAGE ? 0 : s0 + STAGE;
-            const int s2 = s1 == 2 * STAGE ? 0 : s1 + STAGE;
-            ktile(P0{}, T, smem + s0, smem + s1, smem + s2);
-            ktile(P1{}, T + 1, smem + s1, smem + s2, smem + s0);
-            s0 = s2;
-        }
-    }
-    // The last K-tile's barrier is behind every useful LDS read and every LDS-DMA write: the ring is free for the epilogue's
-    // wave-private 4 KiB staging regions (the stale prefetch reads of the last K-tile only ever read).
-    if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
-        const float k1 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f);
-        const float k3 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f);
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            typedef __attribute__((ext_vector_type(2))) float f32x2;
-                            const f32x2 xv = {acc[mh][nh][mi][ni][j], acc[mh][nh][mi][ni][j + 1]};
-                            const f32x2 t = xv * (xv * xv * k3 + k1);
-                            const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-                            const f32x2 o = xv * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-                            acc[mh][nh][mi][ni][j] = o.x; acc[mh][nh][mi][ni][j + 1] = o.y;
-                        }
-    }
-    if constexpr (MODE == MODE_GATE_STORE) {
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const float4 gt = *(const float4*)(e.gate + bn + wc * 64 + nh * 32 + ni * 16 + cq * 4);
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        f32x4& v = acc[mh][nh][mi][ni];
-                        v[0] *= gt.x; v[1] *= gt.y; v[2] *= gt.z; v[3] *= gt.w;
-                    }
-            }
-    }
-    const unsigned st_lane = ((unsigned)(lane >> 3) * (unsigned)ldc + (unsigned)(lane & 7) * 8u) * 2u;     // store: row lane>>3, 16-byte chunk lane&7
-    char* stg = smem + wc * 4096;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int mh = ps >> 1;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int mi = (ps & 1) * 2 + k;
-            const int lr = k * 16 + r16;
-            const int m = bm + ps * 32 + lr;
-            float4 cs4[2][2];
-            bool do_rope = false;
-            int pos = 0;
-            if constexpr (MODE == MODE_QKV_ROPE) {
-                const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim;
-                do_rope = rope_tile && e.cs_q != nullptr;
-                if (rope_tile) {
-                    const int mc = min(m, M - 1);
-                    if (e.cs_by_row) pos = mc;
-                    else if (e.pos_tab) pos = e.pos_tab[mc];
-                    else {
-                        pos = mc - (int)__umulhi((unsigned)mc, e.seq_rcp) * e.seq_n;
-                        if (pos >= e.seq_n) pos -= e.seq_n;
-                    }
-                }
-                if (do_rope) {
-                    const float* tab = (bn + wc * 64 >= e.rope_dim ? e.cs_k : e.cs_q) + (size_t)pos * 64;
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) cs4[nh][ni] = *(const float4*)(tab + nh * 32 + ni * 16 + cq * 4);
-                }
-            }
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    f32x4 v = acc[mh][nh][mi][ni];
-                    const int nl = nh * 32 + ni * 16 + cq * 4;
-                    if constexpr (MODE == MODE_QKV_ROPE) {
-                        if (do_rope) {
-                            const float4 t = cs4[nh][ni];
-                            const float o0 = v[0] * t.x - v[1] * t.y, o1 = v[1] * t.x + v[0] * t.y;
-                            const float o2 = v[2] * t.z - v[3] * t.w, o3 = v[3] * t.z + v[2] * t.w;
-                            v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
-                        } else {
-                            const int n0 = bn + wc * 64 + nl;
-                            if (n0 < 2 * e.rope_dim) {
-                                const bool is_k = n0 >= e.rope_dim;
-                                const int d = n0 & 63;
-                                const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
-                                const float4 sn = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
-                                const float o0 = v[0] * c.x - v[1] * sn.x, o1 = v[1] * c.y + v[0] * sn.y;
-                                const float o2 = v[2] * c.z - v[3] * sn.z, o3 = v[3] * c.w + v[2] * sn.w;
-                                v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
-                            }
-                        }
-                    }
-                    const int chunk = (nl >> 3) ^ (lr & 7);
-                    const bf16x4 pk = __builtin_convertvector(v, bf16x4);
-                    *(bf16x4*)(stg + lr * 128 + chunk * 16 + (nl & 4) * 2) = pk;
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {          // the same wave reads its region back: LDS ops of one wave execute in order
-            const int lr = q * 8 + (lane >> 3);
-            const int ch = lane & 7;
-            const uint4 val = *(const uint4*)(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-            const u32x4 vv = {val.x, val.y, val.z, val.w};
-            const int row_first = bm + ps * 32 + q * 8;                        // wave-uniform
-            const bool ok = (lane >> 3) < M - row_first && bn + wc * 64 + ch * 8 < e.n_store;
-            const unsigned soff = ((unsigned)row_first * (unsigned)ldc + (unsigned)(bn + wc * 64)) * 2u;
-            __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 0);       // dropped when out of range
-        }
-    }
-}
-
 // One-time per-(kernel, device) setup: the dynamic-LDS opt-in is a per-device function attribute, and contexts on several
 // GPUs (or several threads) may reach a launcher's first call at the same time.
 struct KernelSetup {
@@ -1222,23 +872,6 @@ hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, in
     return hipGetLastError();
 }
 
-// gemm_sw_kernel's conditions: bf16 in and out, whole 256-feature tiles, an even number (>= 4) of K-tiles, 31-bit buffer resources
-inline bool sw_fits(int M, int N, int K, int lda, int ldw, int ldc, int act) {
-    return N % 256 == 0 && K % 128 == 0 && K >= 256 && pp_fits(M, N, K, lda, ldw, ldc, 2, act);
-}
-
-template <int MODE>
-hipError_t launch_sw(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e, hipStream_t st) {
-    constexpr int LDS = 3 * 48 * 1024 + 4096;          // + a dump region for range-checked-away pieces (diagnostic variants)
-    static KernelSetup setup;
-    auto kern = gemm_sw_kernel<MODE>;
-    if (hipError_t he = setup.ensure((const void*)kern, LDS, nullptr); he != hipSuccess) return he;
-    const int m_tiles = (M + 127) / 128, n_tiles = N / 256;
-    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    kern<<<grid, 256, LDS, st>>>((const bf16*)A, lda, (const bf16*)W, ldw, (bf16*)C, ldc, M, N, K, e, m_tiles, n_tiles);
-    return hipGetLastError();
-}
-
 template <typename T, int MODE, typename To, int CFG>
 hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                     hipStream_t st) {
@@ -1264,10 +897,6 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     }
     if (e.ks > 1) return hipErrorInvalidValue;                 // a split-K tail exists in the persistent kernel only (vvk_gemm checks)
-    if constexpr (sizeof(T) == 2 && sizeof(To) == 2 && MODE != MODE_GATE_RES) {
-        // single-utterance shapes: one software-pipelined wave per SIMD on 128 x 256 tiles (tile = 128 keeps the plain kernel)
-        if (!big && force_tile == 0 && sw_fits(M, N, K, lda, ldw, ldc, e.act)) return launch_sw<MODE>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
-    }
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
     return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
