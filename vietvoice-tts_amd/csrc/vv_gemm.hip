@@ -467,80 +467,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     // stages, so the counted wait is always vmcnt(8): everything staged more than four phases ago has landed.
     // The last tile of a block "prefetches" itself again (harmless: those slots are free), which keeps the
     // loop free of conditionals; the kernel drains with vmcnt(0) before it exits.
-#ifdef VV_PPH
-    // PPH: both wave groups run the same phase; a phase is ONE barrier interval: the 16 MFMAs of the quadrant with, spread between them,
-    // the LDS reads of what the NEXT half-phase needs (into fragment registers that died with the previous half-phase: no second register
-    // set) and the phase's two LDS-DMA pieces.  Operands are read one phase earlier than in the ping-pong form, so the counted wait is
-    // vmcnt(6): everything staged three or more phases ago has landed.
-    auto rd_w = [&](int nh, int ks, const char* unit) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) wfr[nh][ni][ks] = *(const bf16x8*)(unit + w_row0 + (ni << 11) + lane_off[ks]);
-    };
-    auto rd_a = [&](int ks, const char* unit) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) afr[mi][ks] = *(const bf16x8*)(unit + a_row0 + (mi << 11) + lane_off[ks]);
-    };
-    auto mfma8 = [&](int mh, int nh, int ws, int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[mh][nh][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[ws][ni][ks], afr[mi][ks], acc[mh][nh][mi][ni], 0, 0, 0);
-    };
-    // 8 MFMAs with NR ds_reads and ND buffer loads between them
-#define VV_MIX_STEP(i, NR, ND) do { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); \
-        if constexpr (2 * (i) + 1 < (NR)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); else if constexpr (2 * (i) < (NR)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-        if constexpr ((i) < (ND)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } while (0)
-#define mix(NR, ND) do { VV_MIX_STEP(0, NR, ND); VV_MIX_STEP(1, NR, ND); VV_MIX_STEP(2, NR, ND); VV_MIX_STEP(3, NR, ND); } while (0)
-    auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
-        constexpr bool relaxed = decltype(relaxed_c)::value;
-        const char* base = smem + par * (4 * UNIT);
-        const char* nbase = smem + (par ^ 1) * (4 * UNIT);
-        const bool r1 = T + 1 >= nk, r2 = T + 2 >= nk;          // roll over into the next tile
-        const int bm1 = r1 ? bm_n : bm_c, bn1 = r1 ? bn_n : bn_c, t1 = r1 ? kb_n + T + 1 - nk : kb_c + T + 1;
-        const int bm2 = r2 ? bm_n : bm_c, bn2 = r2 ? bn_n : bn_c, t2 = r2 ? kb_n + T + 2 - nk : kb_c + T + 2;
-#define VV_PPH_END() do { __builtin_amdgcn_sched_barrier(0); if constexpr (relaxed) VV_WAITVM(22); else VV_WAITVM(6); bar(); } while (0)
-        // ---- phase 0: (m0, n0).  k-half 1 of Wn0 / Am0 and all of Wn1 are read beside it
-        rd_w(0, 1, base + 0 * UNIT); rd_a(1, base + 1 * UNIT);
-        stage(T2{}, bm1, bn1, t1, par ^ 1);
-        mfma8(0, 0, 0, 0);
-        mix(6, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_w(1, 0, base + 2 * UNIT); rd_w(1, 1, base + 2 * UNIT);
-        mfma8(0, 0, 0, 1);
-        mix(4, 0);
-        VV_PPH_END();
-        // ---- phase 1: (m0, n1).  Am1's k-half 0 goes into the registers Am0's k-half 0 left
-        stage(T3{}, bm1, bn1, t1, par ^ 1);
-        mfma8(0, 1, 1, 0);
-        mix(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_a(0, base + 3 * UNIT);
-        mfma8(0, 1, 1, 1);
-        mix(4, 0);
-        VV_PPH_END();
-        // ---- phase 2: (m1, n1)
-        rd_a(1, base + 3 * UNIT);
-        stage(T0{}, bm2, bn2, t2, par);
-        mfma8(1, 1, 1, 0);
-        mix(4, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(1, 1, 1, 1);
-        VV_PPH_END();
-        // ---- phase 3: (m1, n0).  The next K-tile's Wn0 / Am0 k-half 0 are read beside its second half
-        stage(T1{}, bm2, bn2, t2, par);
-        mfma8(1, 0, 0, 0);
-        mix(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_w(0, 0, nbase + 0 * UNIT); rd_a(0, nbase + 1 * UNIT);
-        mfma8(1, 0, 0, 1);
-        mix(6, 0);
-        VV_PPH_END();
-#undef VV_PPH_END
-    };
-#undef mix
-#undef VV_MIX_STEP
-#else
     auto ktile = [&](auto relaxed_c, int T, int par, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
         // relaxed: the 16 epilogue stores of the previous tile are still counted by vmcnt (stores and loads retire in issue
         // order); everything this K-tile reads was staged BEFORE them, so the counted wait may leave them in flight too.
@@ -573,7 +499,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     };
 
 
-#endif
     auto ktiles = [&](auto relaxed_c, int& Gc, int bm_c, int bn_c, int bm_n, int bn_n, int kb_c, int kb_n) __attribute__((always_inline)) {
         ktile(relaxed_c, 0, Gc & 1, bm_c, bn_c, bm_n, bn_n, kb_c, kb_n);
         ++Gc;
@@ -602,11 +527,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     }
     VV_WAITVM(8);
     bar();
-#ifdef VV_PPH
-    rd_w(0, 0, smem + 0 * UNIT); rd_a(0, smem + 1 * UNIT);     // k-half 0 of the first K-tile's first quadrant; afterwards read beside phase 3
-#else
     if (g == 1) bar();                                         // stagger group 1 by one segment
-#endif
 
     int G = 0;                                                 // global K-tile counter (LDS parity)
     bool stores_pending = false;
@@ -677,9 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         // (group 1 is in its last cluster), and group 1 re-establishes the stagger with one barrier after its epilogue.
         // (Letting group 0 run its pre-pass and first store pass inside that interval instead of idling was measured: QKV +1.4 %,
         // the rest flat -- profiles/r02/gemm_notes.md.)
-#ifndef VV_PPH
         if (g == 0) bar();
-#endif
 #ifdef VV_GEMM_STAMP
         VV_STAMP(st_e0);
         st_sumW += st_e0 - st_w0;
@@ -858,9 +777,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         VV_STAMP(st_e1);
         st_sumE += st_e1 - st_e0;
 #endif
-#ifndef VV_PPH
         if (g == 1) bar();                                     // group 1 falls one segment behind again
-#endif
     }
 #ifdef VV_GEMM_STAMP
     VV_STAMP(st_end);
@@ -869,9 +786,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         d[0] = st_sumL; d[1] = st_sumB; d[2] = st_sumC; d[3] = st_sumE; d[4] = st_n; d[5] = st_end - st_start; d[6] = (unsigned long long)n_my; d[7] = st_sumS + (st_sumW << 32); d[8] = __builtin_amdgcn_s_memrealtime() - st_rt0;
     }
 #endif
-#ifndef VV_PPH
     if (g == 0) bar();                                         // balance group 1's extra barrier
-#endif
     VV_WAITVM(0);                                              // the self-prefetch of the last tile must land before the LDS is released
 }
 
