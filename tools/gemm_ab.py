@@ -38,6 +38,8 @@ for name, mode, N, K, act in shapes:
         continue
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
+    if os.environ.get("GEMM_AB_ZERO"):          # power probe: all-zero operands toggle (almost) nothing in the matrix pipe -- same instruction stream, lower power
+        A.zero_(); W.zero_()
     bias = (torch.randn(N, generator=g) * 0.1).to(dev)
     gate = torch.randn(N, generator=g).to(dev)
     outs, args = [], []

@@ -27,6 +27,8 @@ for p in libs:
     for name, mode, N, K, act in shapes:
         A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
         W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
+        if os.environ.get("GEMM_AB_ZERO"):      # power probe: same instruction stream on all-zero operands
+            A.zero_(); W.zero_()
         bias = (torch.randn(N, generator=g) * 0.1).to(dev)
         gate = torch.randn(N, generator=g).to(dev)
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
