@@ -265,6 +265,89 @@ def test_gemm_persistent_blocks_walk_several_tiles(hip_tiny, N, K, act):
         assert gu.rel_err(got, ref) < TOL_BF16
 
 
+def test_gemm_headline_shape_every_row(hip_tiny):
+    """The four GEMMs of a DiT block at the HEADLINE size (M = 102,400 rows = 32 utterances x 1,600 frames x 2 branches; dim 1024, FF 2048),
+    EVERY output element against an fp32 product of the same bf16 operands formed on the device: 400 row panels x 4..12 n-tiles over 256
+    persistent workgroups (6.25 - 18.75 tiles each), the split-K tail of the two N = 1024 GEMMs as bench.py runs them, row-gathered
+    rope tables as vv_transformer_steps builds them.  Size-specific faults (a wrong wave tile somewhere in the 1,600..4,800 tiles of a
+    launch) do not show in the small-shape tests above; three launches each, since a timing-dependent one need not show every time."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    M, D, FF, seq_n = 102400, 1024, 2048, 1600
+    g = torch.Generator().manual_seed(102400)
+    x = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+    hid = (torch.randn(M, FF, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+
+    def wgt(n, k):
+        return (torch.randn(n, k, generator=g) / math.sqrt(k)).to(torch.bfloat16).to(dev), (torch.randn(n, generator=g) * 0.1).to(dev)
+
+    def check_rows(got_fn, want_fn, scale):
+        worst = 0.0
+        for lo in range(0, M, 12800):
+            worst = max(worst, float((got_fn(lo, lo + 12800).float() - want_fn(lo, lo + 12800)).abs().max()))
+        assert worst < TOL_BF16 * scale, (worst, scale)
+
+    # ---- QKV + rope (row-gathered compact tables, positions = row % seq_n)
+    Wq, bq = wgt(3 * D, D)
+    pos = (torch.arange(M, dtype=torch.int32) % seq_n).to(dev)
+    ang = torch.repeat_interleave(torch.arange(seq_n, dtype=torch.float32)[:, None] / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))[None, :], 2, dim=1)
+    ropes = [t.contiguous().to(dev) for t in (ang.cos() * 0.125, ang.sin() * 0.125, ang.cos(), ang.sin())]
+    cs = [torch.zeros(seq_n, 64, device=dev) for _ in range(2)]
+    rows = [torch.zeros(M, 64, device=dev) for _ in range(2)]
+    for i in range(2):
+        gu.check(eng, eng.lib.vv_rope_compact(eng.ctx, ropes[2 * i].data_ptr(), ropes[2 * i + 1].data_ptr(), cs[i].data_ptr(), seq_n, gu.stream()))
+        gu.check(eng, eng.lib.vv_rope_rows(eng.ctx, cs[i].data_ptr(), pos.data_ptr(), rows[i].data_ptr(), M, gu.stream()))
+
+    def want_qkv(lo, hi):
+        y = x[lo:hi].float() @ Wq.float().t() + bq
+        p = pos[lo:hi].long()
+        out = y.clone()
+        for part in (0, 1):
+            c, sn = ropes[2 * part][p], ropes[2 * part + 1][p]                       # [rows][64] pair-duplicated
+            v = y[:, part * D:(part + 1) * D].reshape(hi - lo, D // 64, 32, 2)
+            cc, ss = c[:, 0::2].reshape(hi - lo, 1, 32), sn[:, 0::2].reshape(hi - lo, 1, 32)
+            out[:, part * D:(part + 1) * D] = torch.stack((v[..., 0] * cc - v[..., 1] * ss, v[..., 1] * cc + v[..., 0] * ss), dim=-1).reshape(hi - lo, D)
+        return out
+    ref_scale = float((x[:4096].float() @ Wq.float().t() + bq).abs().max())
+    for rep in range(3):
+        got = gu.gemm(eng, x, Wq, bias=bq, mode=1, ropes=ropes + rows, seq_n=seq_n, rope_dim=D, rope_pos=pos, rope_by_row=1)
+        check_rows(lambda lo, hi: got[lo:hi], want_qkv, ref_scale)
+    del got
+
+    # ---- FF1 + tanh-GELU
+    W1, b1 = wgt(FF, D)
+    s1 = float(F.gelu(x[:4096].float() @ W1.float().t() + b1, approximate="tanh").abs().max())
+    for rep in range(3):
+        got = gu.gemm(eng, x, W1, bias=b1, act=1)
+        check_rows(lambda lo, hi: got[lo:hi], lambda lo, hi: F.gelu(x[lo:hi].float() @ W1.float().t() + b1, approximate="tanh"), s1)
+    del got
+
+    # ---- out-projection (K = 1024) and FF2 (K = 2048): gate-store with the split-K tail planned for this device, parts summed as the
+    # consuming LayerNorm does
+    for A, K in ((x, D), (hid, FF)):
+        Wo, bo = wgt(D, K)
+        gate = torch.randn(D, generator=g).to(dev)
+        row0, parts = gu.gemm_tail_plan(eng, M, D, K)
+        so = float((gate * (A[:4096].float() @ Wo.float().t() + bo)).abs().max())
+        for rep in range(3):
+            if parts:
+                Ct = torch.full((parts - 1, M - row0, D), 7.0, dtype=torch.bfloat16, device=dev)
+                got = gu.gemm(eng, A, Wo, bias=bo, mode=3, gate=gate, tail=(Ct, row0, parts))
+                tail_sum = Ct.float().sum(0)
+
+                def got_fn(lo, hi, got=got, tail_sum=tail_sum, row0=row0):
+                    o = got[lo:hi].float()
+                    if hi > row0:
+                        a0 = max(lo, row0)
+                        o[a0 - lo:] += tail_sum[a0 - row0:hi - row0]
+                    return o
+            else:
+                got = gu.gemm(eng, A, Wo, bias=bo, mode=3, gate=gate)
+                got_fn = lambda lo, hi, got=got: got[lo:hi]
+            check_rows(got_fn, lambda lo, hi: gate * (A[lo:hi].float() @ Wo.float().t() + bo), so)
+
+
 def test_gemm_rejects_bad_shapes(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]
@@ -305,6 +388,38 @@ def test_attention(hip_tiny, dtype, seq_n, lens):
         ref = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), v).reshape(seq_n, D)
         got = out[s * seq_n:(s + 1) * seq_n]
         assert gu.rel_err(got[:L], ref[:L]) < _tol(dtype), (s, gu.rel_err(got[:L], ref[:L]))
+
+
+def test_attention_headline_shape_every_row(hip_tiny):
+    """bf16 attention at the headline size (64 sequences = 32 utterances x 2 branches, 1,600 frames, 16 heads of 64): every output row
+    of every sequence against an fp32 softmax(QK^T)V of the same bf16 operands formed on the device, uniform lengths (what bench.py runs)
+    and ragged key lengths (masked tails, speculative-softmax redo on the partial last tile)."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    n_seq, seq_n, heads, D = 64, 1600, 16, 1024
+    g = torch.Generator().manual_seed(6416)
+    qkv = torch.randn(n_seq * seq_n, 3 * D, generator=g)
+    qkv[:, :D] *= 0.35                                                  # q carries the 1/sqrt(64) of the rope tables in the path
+    qkv = qkv.to(torch.bfloat16).to(dev)
+    lens_ragged = [seq_n - (37 * s_) % 900 for s_ in range(n_seq)]
+    for lens in ([seq_n] * n_seq, lens_ragged):
+        out = torch.zeros(n_seq * seq_n, D, dtype=torch.bfloat16, device=dev)
+        kv = torch.tensor(lens, dtype=torch.int32, device=dev)
+        a = rt.vv_attn_args()
+        a.dtype = rt.VV_BF16
+        a.qkv, a.ld_qkv, a.out, a.ld_out = qkv.data_ptr(), 3 * D, out.data_ptr(), D
+        a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len = n_seq, seq_n, heads, D, kv.data_ptr()
+        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        worst = 0.0
+        for s_, L in enumerate(lens):
+            f = qkv[s_ * seq_n:(s_ + 1) * seq_n].float().reshape(seq_n, 3, heads, 64)
+            sc = torch.einsum("qhd,khd->hqk", f[:, 0], f[:L, 1])
+            ref = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), f[:L, 2]).reshape(seq_n, D)
+            got = out[s_ * seq_n:(s_ + 1) * seq_n].float()
+            worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+        assert worst < TOL_BF16, (worst, lens[:4])
 
 
 def test_attention_spiked_max(hip_tiny):
