@@ -495,6 +495,57 @@ def test_layernorm_modulate(hip_tiny, D, out_dtype):
         assert gu.rel_err(y, F.layer_norm(xn2, (D,), eps=1e-6) * (sc + 1) + sh) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5)
 
 
+def test_layernorm_headline_shape_every_row(hip_tiny):
+    """The block's two LayerNorm passes at the headline size (102,400 rows x 1024): the residual stream after the fused adds is EXACT
+    (x + d1, then (x + d1) + d2 with both deltas' split-K tail parts, fp32 adds in the kernel's order) on every row, keep_x leaves x
+    untouched, and the modulated bf16 output matches an fp32 LayerNorm of that stream on every row."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    R, D = 102400, 1024
+    g = torch.Generator().manual_seed(10241024)
+    x = (torch.randn(R, D, generator=g) * 2 + 0.25).to(dev)
+    sc, sh = (torch.randn(D, generator=g) * 0.3).to(dev), (torch.randn(D, generator=g) * 0.3).to(dev)
+    d1 = (torch.randn(R, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    d2 = (torch.randn(R, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    row0, parts = gu.gemm_tail_plan(eng, R, D, 1024)
+    assert parts >= 2 and 0 < row0 < R, "the headline shape has a split-K tail on a 256-CU device"
+    t1 = (torch.randn(parts - 1, R - row0, D, generator=g) * 0.25).to(torch.bfloat16).to(dev)
+    t2 = (torch.randn(parts - 1, R - row0, D, generator=g) * 0.25).to(torch.bfloat16).to(dev)
+    y = torch.zeros(R, D, dtype=torch.bfloat16, device=dev)
+    xx = x.clone()
+    a = rt.vv_ln_args()
+    a.out_dtype = rt.VV_BF16
+    a.x, a.ldx, a.y, a.ldy, a.R, a.D, a.w, a.b, a.add_one, a.eps = xx.data_ptr(), D, y.data_ptr(), D, R, D, sc.data_ptr(), sh.data_ptr(), 1, 1e-6
+    a.delta, a.delta_dtype, a.ld_delta = d1.data_ptr(), rt.VV_BF16, D
+    a.tail_row0, a.delta_tail, a.delta_tail_parts = row0, t1.data_ptr(), parts
+    a.keep_x = 1
+    gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xx, x)
+    def with_tail(d, t):                      # the kernel's order: the delta and its K parts are summed first, then added to the stream
+        e = d.float()
+        for p_ in range(parts - 1):
+            e[row0:] = e[row0:] + t[p_].float()
+        return e
+    s1 = x + with_tail(d1, t1)
+
+    def ln_err(stream):
+        worst = 0.0
+        for lo in range(0, R, 12800):
+            ref = F.layer_norm(stream[lo:lo + 12800], (D,), eps=1e-6) * (sc + 1) + sh
+            worst = max(worst, float((y[lo:lo + 12800].float() - ref).abs().max() / ref.abs().max()))
+        return worst
+    assert ln_err(s1) < 1e-2
+    a.keep_x = 0
+    a.delta2, a.delta2_tail, a.delta2_tail_parts = d2.data_ptr(), t2.data_ptr(), parts
+    gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
+    torch.cuda.synchronize()
+    s2 = s1 + with_tail(d2, t2)
+    assert torch.equal(xx, s2), float((xx - s2).abs().max())
+    assert ln_err(s2) < 1e-2
+
+
 @pytest.mark.parametrize("N,K,m_tiles,ragged", [(512, 512, 136, 100), (1024, 1024, 68, 0), (1024, 4096, 80, 255), (512, 256, 136, 0)])
 def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
     """Split-K tail of the persistent gate-store GEMM (vv_gemm_tail_plan): rows below row0 are bit-identical to the plain
