@@ -18,6 +18,8 @@ g = torch.Generator().manual_seed(0)
 qkv = torch.randn(n_seq * N, 3 * D, generator=g)
 qkv[:, :D] *= 0.125
 qkv = qkv.to(torch.bfloat16).to(dev)
+if os.environ.get("ATTN_AB_ZERO"):          # power probe: the same instruction stream on all-zero q / k / v (uniform softmax, no redo path after tile 0)
+    qkv.zero_()
 engs, outs = [], []
 for p in libs:
     rt._lib = None
