@@ -45,7 +45,6 @@ __device__ __forceinline__ float half_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-#ifdef VV_ATTN_ASMDMA
 // LDS-DMA as an asm statement (cdna guide, 'What hipcc does not do' item 1): hipcc treats the builtin form as a write to the LDS array
 // and puts an s_waitcnt vmcnt(0) in front of the next ds_read of that array -- here in front of PV, right behind the next tile's
 // staging loads.  The asm form is outside its bookkeeping: its completion is the explicit vmcnt(0) + barrier at the top of a tile.
@@ -64,7 +63,6 @@ __device__ __forceinline__ void glds16_buf_asm(i32x4_t rs, unsigned voff, unsign
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
-#endif
 
 // Workgroup -> (query block, head, sequence), XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs by linear id, and each
 // XCD has its own L2: with a plain (q-block, head, seq) grid the 13 query blocks that share one (sequence, head)'s K/V land on
@@ -118,16 +116,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
     }
 
-    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  buffer_load ... lds
+    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  buffer_load ... lds (as asm
+    // statements: glds16_buf_asm -- 689 -> 676 us at the bench shape against the builtin, bit-identical, profiles/r03/attn_ab_asm_stage.txt)
     // with a per-lane byte offset that advances by one add per piece and tile (the advance stays in the VGPR offset: the
     // SGPR offset of a buffer instruction is not range-checked).  Rows past the end of the buffer (last tile of the last
     // sequence) read as zero instead of needing a clamp; rows past the sequence but inside the buffer are the next
     // sequence's (finite data) and are masked like any key >= kv_len.
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)kv_bytes, 0x00020000);
-#ifdef VV_ATTN_ASMDMA
-    const i32x4_t rs4 = make_rsrc4(Kp, kv_bytes);
+    const i32x4_t rs4 = make_rsrc4(Kp, kv_bytes);          // buffer resource of the K/V columns: base Kp, kv_bytes records (raw, range-checked)
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-#endif
     unsigned voff_k[2], voff_v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -140,17 +136,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     }
     const int tile_bytes = 64 * ld * 2;
     auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * 16384;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = wave * 2 + u;
-#ifdef VV_ATTN_ASMDMA
             glds16_buf_asm(rs4, voff_k[u] + kt * tile_bytes, lds0 + buf * 16384 + q * 1024);
             glds16_buf_asm(rs4, voff_v[u] + kt * tile_bytes, lds0 + buf * 16384 + 8192 + q * 1024);
-#else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + q * 1024), 16, (int)(voff_k[u] + kt * tile_bytes), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + 8192 + q * 1024), 16, (int)(voff_v[u] + kt * tile_bytes), 0, 0, 0);
-#endif
         }
     };
 
@@ -240,22 +230,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // which path ran.
         float psum = 0.f;
         bool redo = kt == 0;
-#if defined(VV_ATTN_STAGE_TOP)
-        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-        if (!redo) {
-            scores();
-            psum = exps();
-            redo = __any(!(psum <= RESCALE_SUM));
-        }
-#elif defined(VV_ATTN_STAGE_MID)
-        if (!redo) {
-            scores();
-            if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-            psum = exps();
-            redo = __any(!(psum <= RESCALE_SUM));
-        }
-        else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-#else
         if (!redo) {
             scores();
             psum = exps();
@@ -263,7 +237,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             redo = __any(!(psum <= RESCALE_SUM));
         }
         else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
-#endif
         if (redo) {
             scores();
             float mx = s[0][0];
@@ -326,228 +299,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 store4<bf16>(op + d0, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
                              o[dt][4 * g + 3] * inv);
             }
-    }
-}
-
-// ------------------------------------------------------------------------------------ bf16, 16x16x32 form
-// Same workgroup, staging and online softmax as attn_bf16_kernel, on v_mfma_f32_16x16x32_bf16 (the shape the chip clocks higher on
-// random operands: MI355X_MICROARCH.md 'DVFS give-back' item 7).  Lane (r16 = lane & 15, cq = lane >> 4) owns queries r16 and 16 + r16
-// of the wave's 32; a 16 x 16 block of S^T puts keys 4cq .. 4cq+3 of the block on its four registers, so
-//   * the row reference rides in for free: the first MFMA of a block takes C = (-m, -m, -m, -m) of the lane's query (four registers
-//     per query block) instead of the 65th contraction element's two extra MFMAs per tile;
-//   * registers of key blocks 2s and 2s+1 are, converted, the B fragment of PV's k-step s (k = 8cq + e  <->  key (2s + (e >> 2)) 16 +
-//     4cq + (e & 3)); the V^T fragment takes the same keys: two transposed reads of 4 keys x 16 d per 16-lane group;
-//   * partial row sums / maxima are per lane over its 16 keys of a tile and meet across the four cq lanes only at the end (and in
-//     the rare careful path).
-__global__ __launch_bounds__(256, 4) void attn_bf16_16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
-                                                              int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                              const int* __restrict__ row_start, int total_rows, int heads, int n_seq) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
-    const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
-    if (!blk.valid) return;
-    const int head = blk.head, seq = blk.seq, qblock = blk.qb;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r16 = lane & 15, cq = lane >> 4;
-    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
-    kv_len = max(1, min(kv_len, seq_n));
-    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
-    const int q_lim = row_start ? kv_len : seq_n;
-    if (qblock * 128 >= q_lim) return;
-
-    const bf16* Qp = qkv + row0 * ld + head * 64;
-    const bf16* Kp = Qp + D;
-    const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
-
-    const int q0 = qblock * 128 + wave * 32;
-    bf16x8 qf[2][2];                               // [query block][k-step]: B operand, k = d = 32 ks + 8 cq + j, scores in the log2 domain
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = min(q0 + qb * 16 + r16, q_lim - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[qb][ks] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ks * 32 + cq * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (bf16)((float)qf[qb][ks][j] * LOG2E);
-        }
-    }
-
-    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)kv_bytes, 0x00020000);
-#ifdef VV_ATTN_ASMDMA
-    const i32x4_t rs4 = make_rsrc4(Kp, kv_bytes);
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-#endif
-    // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  V's swizzle has period 8 rows,
-    // so its second piece is the first one 8 rows further on (one offset register); K's swz128 is not.
-    unsigned voff_k[2], voff_v;
-    {
-        const int p = lane & 7;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = (wave * 2 + u) * 8 + (lane >> 3);
-            voff_k[u] = (unsigned)row * (unsigned)ld * 2u + (p ^ ((row >> 1) & 7)) * 16;          // swz128 (row reads, ds_read_b128)
-        }
-        const int row = wave * 16 + (lane >> 3);
-        // V: 32-byte d-block index ^ (row >> 1) & 3 -- conflict-free transposed reads of 8 consecutive keys per 32-lane half
-        voff_v = (unsigned)row * (unsigned)ld * 2u + (unsigned)D * 2u + (p ^ (((row >> 1) & 3) << 1)) * 16;
-    }
-    const int tile_bytes = 64 * ld * 2;
-    auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * 16384;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = wave * 2 + u;
-#ifdef VV_ATTN_ASMDMA
-            glds16_buf_asm(rs4, voff_k[u] + kt * tile_bytes, lds0 + buf * 16384 + q * 1024);
-            glds16_buf_asm(rs4, voff_v + kt * tile_bytes + u * 8 * ld * 2, lds0 + buf * 16384 + 8192 + q * 1024);
-#else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + q * 1024), 16, (int)(voff_k[u] + kt * tile_bytes), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)(base + 8192 + q * 1024), 16, (int)(voff_v + kt * tile_bytes + u * 8 * ld * 2), 0, 0, 0);
-#endif
-        }
-    };
-
-    f32x4 o[4][2];                                 // [d block][query block]: O^T, d = 16 db + 4 cq + j
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) o[db][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_eff[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
-
-    // K row read: lane (r16 = key of the block, cq = 16-byte chunk of the k-step); k-step 1 is the same row's chunk + 4 = offset ^ 64
-    // (key block kb adds 16 rows: (row >> 1) & 7 does not see it)
-    const int k_off0 = swz128(r16, cq);
-    // V transposed read: lane 4q + p of group cq supplies row (key) 4cq + q of the 16-key block, d columns 16 db + 4p .. + 3;
-    // d block db sits at 32-byte slot db ^ ((row >> 1) & 3): offset of block db = offset of block 0 ^ (db << 5)
-    const int tq = (lane >> 2) & 3, tp = lane & 3;
-    const int tr_off0 = (cq * 4 + tq) * 128 + ((((tp >> 1)) ^ ((((cq * 4 + tq) >> 1) & 3) << 1)) << 4) + (tp & 1) * 8;
-
-    const int n_tiles = (kv_len + 63) / 64;
-    stage(0, 0);
-    bool retry = false;                            // the speculative pass of this tile overflowed: run it again the careful way
-    for (int kt = 0; kt < n_tiles;) {
-        if (!retry) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        const int kbase = kt * 64;
-        const bool careful = retry || kt == 0;
-        // ---- S'^T = K Q^T - m: scores in the log2 domain, already shifted by the row reference (C operand of the first MFMA)
-        f32x4 s[2][4];                             // [query block][key block]: key = kbase + 16 kb + 4 cq + j
-        {
-            const f32x4 negm[2] = {(f32x4){-m_eff[0], -m_eff[0], -m_eff[0], -m_eff[0]}, (f32x4){-m_eff[1], -m_eff[1], -m_eff[1], -m_eff[1]}};
-            const int ko = (kt & 1) * 16384 + k_off0;          // byte offsets inside smem (XOR on offsets, not on pointers: the reads stay ds_read)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const bf16x8 kf0 = *(const bf16x8*)(smem + (ko + kb * 2048));
-                const bf16x8 kf1 = *(const bf16x8*)(smem + ((ko ^ 64) + kb * 2048));
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], negm[qb], 0, 0, 0);
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], s[qb][kb], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (kbase + 64 > kv_len) {
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (kbase + kb * 16 + cq * 4 + j >= kv_len) { s[0][kb][j] = NEG_BIG; s[1][kb][j] = NEG_BIG; }
-            }
-        }
-        // Online softmax with a SPECULATIVE tile (as attn_bf16_kernel): exponentials against the stale reference first; a partial row sum
-        // above 2^8 sends the tile round again through the careful fix-up (row max, reference moved, O and l rescaled, scores re-shifted).
-        if (careful) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                float mx = s[qb][0][0];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qb][kb][j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));                 // the other three cq lanes hold the other 48 keys of the same query
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = bf16_round(kt == 0 ? mx : m_eff[qb] + fmaxf(mx, 0.f));
-                const float d = m_new - m_eff[qb];
-                if (kt != 0) {
-                    const float alpha = fast_exp2(-d);
-                    l_run[qb] *= alpha;
-#pragma unroll
-                    for (int db = 0; db < 4; ++db)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[db][qb][j] *= alpha;
-                }
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) s[qb][kb][j] -= d;    // this tile was shifted by the old reference
-                m_eff[qb] = m_new;
-            }
-        }
-        // p = 2^s' in place + partial row sums.  Single v_add_f32 on purpose: hipcc packs adjacent adds into v_pk_add_f32, which issues
-        // slowly beside MFMAs on gfx950 (an empty asm on one chain keeps them apart).
-        float psum[2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float pv = fast_exp2(s[qb][kb][j]);
-                    if (j & 1) { ps1 += pv; asm("" : "+v"(ps1)); }       // opaque: keeps the two chains out of one v_pk_add_f32
-                    else ps0 += pv;
-                    s[qb][kb][j] = pv;
-                }
-            psum[qb] = ps0 + ps1;
-        }
-        if (!retry && kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);       // once per tile, between the exponentials and PV
-        if (!careful && __any(!(fmaxf(psum[0], psum[1]) <= RESCALE_SUM))) { retry = true; continue; }
-        retry = false;
-        l_run[0] += psum[0];
-        l_run[1] += psum[1];
-
-        // ---- O^T += V^T P^T
-        const int vo = (kt & 1) * 16384 + 8192 + tr_off0;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 pf[2];
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const f32x8 pv = {s[qb][2 * st][0], s[qb][2 * st][1], s[qb][2 * st][2], s[qb][2 * st][3],
-                                  s[qb][2 * st + 1][0], s[qb][2 * st + 1][1], s[qb][2 * st + 1][2], s[qb][2 * st + 1][3]};
-                pf[qb] = __builtin_convertvector(pv, bf16x8);
-            }
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const char* a0 = smem + ((vo ^ (db << 5)) + (32 * st) * 128);
-                const char* a1 = a0 + 16 * 128;
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
-                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        ++kt;
-    }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        float l_tot = l_run[qb];
-        l_tot += __shfl_xor(l_tot, 16);
-        l_tot += __shfl_xor(l_tot, 32);
-        const float inv = 1.0f / l_tot;
-        const int q = q0 + qb * 16 + r16;
-        if (q < q_lim) {
-            bf16* op = out + (row0 + q) * ldo + head * 64;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-                store4<bf16>(op + db * 16 + cq * 4, o[db][qb][0] * inv, o[db][qb][1] * inv, o[db][qb][2] * inv, o[db][qb][3] * inv);
-        }
     }
 }
 
@@ -708,12 +459,6 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const long long pairs8 = ((long long)a->heads * a->n_seq + 7) / 8;          // (sequence, head) pairs per XCD group
     if (pairs8 * nqb * 8 > 0x7fffffffLL) { *err = "attention: grid too large"; return -22; }
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
-#ifdef VV_ATTN16
-    if (a->dtype == VV_BF16)
-        attn_bf16_16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                                  a->heads, a->n_seq);
-    else
-#endif
     if (a->dtype == VV_BF16)
         attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
                                                a->heads, a->n_seq);
