@@ -10,7 +10,8 @@ Work per utterance follows
 SURVEY.md 8(d): T = 256 ids (96 reference + 160 target), 6.0 s reference clip (144,000 samples ->
 563 frames), 1037 generated frames, N = 1600 frames, 265,472 output samples = 11.061 s of audio.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N = 1)
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1 without a launcher: starts the N ranks itself, as a child
+                                                            `python -m torch.distributed.run` on 127.0.0.1, and relays their output)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, rank 0 packs the weights and RCCL-broadcasts the flat buffer over xGMI,
@@ -200,14 +201,32 @@ def main():
     if a.workload == "longform":
         return longform(a)
 
+    backend = os.environ.get("VV_BENCH_DIST_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the N>1 path (ranks share cuda:0)
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, as a CHILD process tree --
+        # before anything in this process has touched the GPU (device_count() does not initialise it) and never by exec -- pass the
+        # children's output through and exit with their return code.  Without this a bare --gpus 8 would run one rank and report n_gpus 1.
+        import socket
+        import subprocess
+        if backend == "nccl" and torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the synthesis hot path has no CPU fallback")
-    backend = os.environ.get("VV_BENCH_DIST_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the N>1 path (ranks share cuda:0)
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -297,6 +316,11 @@ def main():
     else:
         audio_s_all = audio_s_rank
 
+    devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}"]
+    if dist is not None:                                  # which card every rank ran on (two ranks on one card = a rehearsal, and says so)
+        got = [None] * world
+        dist.all_gather_object(got, devices[0])
+        devices = got
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -377,8 +401,10 @@ def main():
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
         "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
     }
+    res["devices"] = devices
     if bcast_ms is not None:
         res["weight_pack_and_broadcast_ms"] = round(bcast_ms, 2)
+        res["dist_backend"] = "nccl (RCCL)" if backend == "nccl" else backend + " (rehearsal: ranks may share a card)"
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(spec, weights, a.nfe)
     print(json.dumps(res), flush=True)

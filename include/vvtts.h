@@ -125,8 +125,9 @@ VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the co
  * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way.
  * "split_k_tail" (bf16 acoustic model): lets vv_transformer_steps take vv_gemm_tail_plan's split-K tail -- 0 never, 1 for the
  * out-projection and FF2 GEMMs, 2 (default) for FF2 only (the measured optimum at the flagship shape: the parts cost the
- * consuming norms extra reads).  Rows in the tail sum bf16-rounded K parts in fp32 (same tolerance class as the plain launch,
- * not bit-identical to it); the fp32 path never splits.
+ * consuming norms extra reads).  The K parts of a tail row are kept in fp32, summed by the consuming norm and the SUM rounded to
+ * bf16 once, where a row outside the tail is rounded in the GEMM epilogue: a tail row differs from the plain launch by fp32
+ * summation order only (a row's result does not depend on its position in the launch); the fp32 path never splits.
  * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
@@ -160,8 +161,9 @@ typedef struct vv_gemm_args {
     int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
                                   needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */
     int32_t tail_parts, tail_row0;   /* split-K tail (VV_EPI_GATE_STORE, bf16): both exactly as vv_gemm_tail_plan returns them, 0 = off */
-    void* C_tail;              /* tail_parts > 1: [tail_parts - 1][M - tail_row0][ldc] partial products of rows >= tail_row0; C holds
-                                  part 0 (with the bias), the consumer adds the rest (vv_ln_args.delta_tail) */
+    void* C_tail;              /* tail_parts > 1: fp32 [tail_parts][M - tail_row0][ldc] gated products of the K parts of rows >= tail_row0
+                                  (part 0 carries the bias); those rows of C are NOT written: the consumer sums the parts and rounds
+                                  the sum to the output dtype once (vv_ln_args.delta_tail) */
 } vv_gemm_args;
 VV_API int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 /* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the
@@ -196,9 +198,9 @@ typedef struct vv_ln_args {
     int32_t delta_dtype, ld_delta;
     const void* delta2;     /* optional second delta (same dtype / ld): y = LN((x + delta) + delta2) */
     int32_t keep_x;         /* 1: normalise x + delta but leave x as it is (the caller adds this delta again later, with delta2) */
-    int32_t tail_row0;      /* split-K tails of the deltas (vv_gemm_args.C_tail): rows >= tail_row0 also add */
-    int32_t delta_tail_parts, delta2_tail_parts;   /*   delta_tail [parts - 1][R - tail_row0][ld_delta] (0 / 1 parts = none)  */
-    const void *delta_tail, *delta2_tail;          /*   in part order, right after the delta they belong to                   */
+    int32_t tail_row0;      /* split-K tails of the deltas (vv_gemm_args.C_tail): for rows >= tail_row0 the delta is NOT read;    */
+    int32_t delta_tail_parts, delta2_tail_parts;   /*   it is the sum, in part order, of fp32 delta_tail [parts][R - tail_row0][ld_delta] */
+    const void *delta_tail, *delta2_tail;          /*   rounded once to delta_dtype (0 / 1 parts = none)                       */
 } vv_ln_args;
 VV_API int vv_layernorm(vv_ctx* ctx, const vv_ln_args* args, void* stream);
 

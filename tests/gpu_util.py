@@ -28,14 +28,15 @@ def gemm_tail_plan(eng, M, N, K):
 
 
 def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0, tile=0,
-         rope_pos=None, rope_by_row=0, tail=None):
-    """A [M,K], W [N,K] on device, same dtype (bf16 or f32).  tail = (C_tail tensor, row0, parts): the split-K tail request."""
+         rope_pos=None, rope_by_row=0, tail=None, c_fill=0.0):
+    """A [M,K], W [N,K] on device, same dtype (bf16 or f32).  tail = (fp32 C_tail tensor [parts][M - row0][N], row0, parts): the
+    split-K tail request.  c_fill: what a fresh output buffer holds before the launch (shows rows the kernel leaves unwritten)."""
     dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
     od = dt if out_dtype is None else out_dtype
     M, K = A.shape
     N = W.shape[0]
     if C_io is None:
-        C_io = torch.zeros((M, N), dtype=torch.bfloat16 if od == rt.VV_BF16 else torch.float32, device=DEV)
+        C_io = torch.full((M, N), c_fill, dtype=torch.bfloat16 if od == rt.VV_BF16 else torch.float32, device=DEV)
     a = rt.vv_gemm_args()
     a.dtype, a.out_dtype, a.mode, a.act = dt, od, mode, act
     a.A, a.lda, a.W, a.ldw, a.C, a.ldc = A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C_io.data_ptr(), C_io.stride(0)

@@ -267,6 +267,20 @@ def test_bench_two_rank_branch_over_gloo():
     assert d["weight_pack_and_broadcast_ms"] > 0 and "cpu_baseline" not in d         # cpu_baseline is an N = 1 leg
     per_rank_audio = 4 * 1037 * 256 / 24000.0
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * per_rank_audio) < 0.02 * per_rank_audio      # value = SUM of audio over ranks / MAX time
+    assert len(d["devices"]) == 2 and d["devices"][0].startswith("rank 0: cuda:") and d["devices"][1].startswith("rank 1: cuda:")
+    # the form the driver uses for N = 1, with N = 2 and NO launcher: bench.py must start the two ranks itself (a child
+    # torch.distributed.run), not run one rank and label it --gpus 2
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny", "--steps", "1", "--warmup", "0", "--batch", "4"],
+                        capture_output=True, text=True, timeout=900, cwd=root, env=env2)
+    assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-3000:])
+    lines2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines2) == 1, r2.stdout[-2000:]
+    d2 = json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 8 and len(d2["devices"]) == 2 and d2["weight_pack_and_broadcast_ms"] > 0
+    # a launcher whose rank count disagrees with --gpus is refused, not silently relabelled
+    bad = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["3"] + cmd[cmd.index("--gpus") + 2:], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 @pytest.mark.parametrize("graph", [False, True])

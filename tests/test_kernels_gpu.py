@@ -265,6 +265,14 @@ def test_gemm_persistent_blocks_walk_several_tiles(hip_tiny, N, K, act):
         assert gu.rel_err(got, ref) < TOL_BF16
 
 
+def _tail_sum(Ct):
+    """What vv_layernorm makes of a split-K tail: the fp32 K parts summed in part order, the sum rounded to bf16 once."""
+    acc = Ct[0].clone()
+    for p_ in range(1, Ct.shape[0]):
+        acc = acc + Ct[p_]
+    return acc.to(torch.bfloat16)
+
+
 def test_gemm_headline_shape_every_row(hip_tiny):
     """The four GEMMs of a DiT block at the HEADLINE size (M = 102,400 rows = 32 utterances x 1,600 frames x 2 branches; dim 1024, FF 2048),
     EVERY output element against an fp32 product of the same bf16 operands formed on the device: 400 row panels x 4..12 n-tiles over 256
@@ -332,15 +340,15 @@ def test_gemm_headline_shape_every_row(hip_tiny):
         so = float((gate * (A[:4096].float() @ Wo.float().t() + bo)).abs().max())
         for rep in range(3):
             if parts:
-                Ct = torch.full((parts - 1, M - row0, D), 7.0, dtype=torch.bfloat16, device=dev)
+                Ct = torch.full((parts, M - row0, D), 7.0, dtype=torch.float32, device=dev)
                 got = gu.gemm(eng, A, Wo, bias=bo, mode=3, gate=gate, tail=(Ct, row0, parts))
-                tail_sum = Ct.float().sum(0)
+                tail_sum = _tail_sum(Ct)                  # fp32 K parts in part order, rounded once: the delta the LayerNorm forms
 
                 def got_fn(lo, hi, got=got, tail_sum=tail_sum, row0=row0):
                     o = got[lo:hi].float()
                     if hi > row0:
                         a0 = max(lo, row0)
-                        o[a0 - lo:] += tail_sum[a0 - row0:hi - row0]
+                        o[a0 - lo:] = tail_sum[a0 - row0:hi - row0].float()      # the tail rows of C are not written
                     return o
             else:
                 got = gu.gemm(eng, A, Wo, bias=bo, mode=3, gate=gate)
@@ -510,8 +518,10 @@ def test_layernorm_headline_shape_every_row(hip_tiny):
     d2 = (torch.randn(R, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     row0, parts = gu.gemm_tail_plan(eng, R, D, 1024)
     assert parts >= 2 and 0 < row0 < R, "the headline shape has a split-K tail on a 256-CU device"
-    t1 = (torch.randn(parts - 1, R - row0, D, generator=g) * 0.25).to(torch.bfloat16).to(dev)
-    t2 = (torch.randn(parts - 1, R - row0, D, generator=g) * 0.25).to(torch.bfloat16).to(dev)
+    t1 = (torch.randn(parts, R - row0, D, generator=g) * 0.25).to(dev)          # fp32 K parts of the tail rows (the delta's own tail rows are not read)
+    t2 = (torch.randn(parts, R - row0, D, generator=g) * 0.25).to(dev)
+    d1[row0:] = float("nan")
+    d2[row0:] = float("nan")
     y = torch.zeros(R, D, dtype=torch.bfloat16, device=dev)
     xx = x.clone()
     a = rt.vv_ln_args()
@@ -523,10 +533,9 @@ def test_layernorm_headline_shape_every_row(hip_tiny):
     gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
     torch.cuda.synchronize()
     assert torch.equal(xx, x)
-    def with_tail(d, t):                      # the kernel's order: the delta and its K parts are summed first, then added to the stream
+    def with_tail(d, t):                      # the kernel's order: the K parts are summed in fp32, the sum rounded to bf16 once, then added to the stream
         e = d.float()
-        for p_ in range(parts - 1):
-            e[row0:] = e[row0:] + t[p_].float()
+        e[row0:] = _tail_sum(t).float()
         return e
     s1 = x + with_tail(d1, t1)
 
@@ -549,8 +558,10 @@ def test_layernorm_headline_shape_every_row(hip_tiny):
 @pytest.mark.parametrize("N,K,m_tiles,ragged", [(512, 512, 136, 100), (1024, 1024, 68, 0), (1024, 4096, 80, 255), (512, 256, 136, 0)])
 def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
     """Split-K tail of the persistent gate-store GEMM (vv_gemm_tail_plan): rows below row0 are bit-identical to the plain
-    launch; for rows >= row0 part 0 (+ bias) lands in C and the other K parts in C_tail, and their fp32 sum matches the
-    fp32 product of the same bf16 operands.  Then the consumer: vv_layernorm with delta_tail adds exactly that sum.
+    launch; for rows >= row0 every K part (part 0 with the bias) lands in the fp32 buffer C_tail and C's tail rows stay
+    unwritten; the parts summed in fp32 and rounded to bf16 ONCE equal the plain launch's rows except where the fp32
+    summation order flips a bf16 rounding (round 4: a row's result no longer depends on its position in the launch).
+    Then the consumer: vv_layernorm with delta_tail forms exactly that rounded sum.
     The last case has too few K-tiles for 4 parts (2 K-tiles each are the minimum) and must take 2."""
     rt, gu = _imports()
     eng = hip_tiny["f32"]
@@ -569,18 +580,22 @@ def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
     plain = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate)
     want = gate * (A.float() @ W.float().t() + b)
     for rep in range(2):
-        Ct = torch.full((parts - 1, M - row0, N), 7.0, dtype=torch.bfloat16, device=gu.DEV)
-        got = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, tail=(Ct, row0, parts))
+        Ct = torch.full((parts, M - row0, N), 7.0, dtype=torch.float32, device=gu.DEV)
+        got = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, tail=(Ct, row0, parts), c_fill=3.0)
         assert torch.equal(got[:row0], plain[:row0])
-        total = got[row0:].float() + Ct.float().sum(0)
+        assert bool((got[row0:] == 3.0).all()), "the tail rows of C are left to the consumer"
+        total = _tail_sum(Ct)
         assert gu.rel_err(total, want[row0:]) < TOL_BF16
-        assert gu.rel_err(total, plain[row0:].float()) < TOL_BF16
+        # position independence: the rounded sum IS the plain launch's row, up to bf16 roundings flipped by the fp32 summation order
+        flips = (total != plain[row0:])
+        assert float(flips.float().mean()) < 2e-3, float(flips.float().mean())
+        assert float((total.float() - plain[row0:].float()).abs().max()) <= 2.0 ** -7 * float(plain[row0:].float().abs().max())     # one bf16 ulp
         assert not bool((Ct == 7.0).all(dim=-1).any()), "every tail row of every part is written"
-        # the parts really are K ranges: part p alone equals gate * A[:, p-th K range] W^T
+        # the parts really are K ranges: part p alone equals gate * (A[:, p-th K range] W^T [+ bias for part 0]), to fp32 accuracy
         kq = K // parts
-        for p_ in range(1, parts):
-            wp = gate * (A[row0:, p_ * kq:(p_ + 1) * kq].float() @ W[:, p_ * kq:(p_ + 1) * kq].float().t())
-            assert gu.rel_err(Ct[p_ - 1], wp) < TOL_BF16, p_
+        for p_ in range(parts):
+            wp = gate * (A[row0:, p_ * kq:(p_ + 1) * kq].float() @ W[:, p_ * kq:(p_ + 1) * kq].float().t() + (b if p_ == 0 else 0.0))
+            assert gu.rel_err(Ct[p_], wp) < 1e-4, p_
     # a request that is not the plan for the shape is refused, not guessed at
     a_bad = (Ct, row0 + 2048, parts)
     with pytest.raises(AssertionError, match="split-K tail"):
@@ -594,7 +609,7 @@ def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
     sc, sh = (torch.randn(N, generator=g) * 0.3).to(gu.DEV), (torch.randn(N, generator=g) * 0.3).to(gu.DEV)
     y = torch.zeros(M, N, dtype=torch.bfloat16, device=gu.DEV)
     d2 = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(gu.DEV)
-    d2t = (torch.randn(1, M - row0, N, generator=g) * 0.5).to(torch.bfloat16).to(gu.DEV)
+    d2t = (torch.randn(2, M - row0, N, generator=g) * 0.5).to(gu.DEV)
     for two in (False, True):
         xx = x.clone()
         a = rt.vv_ln_args()
@@ -607,11 +622,11 @@ def test_gemm_split_k_tail(hip_tiny, N, K, m_tiles, ragged):
         gu.check(eng, eng.lib.vv_layernorm(eng.ctx, C.byref(a), gu.stream()))
         torch.cuda.synchronize()
         dsum = got.float()
-        dsum[row0:] = (((got[row0:].float() + Ct[0].float()) + Ct[1].float()) + Ct[2].float())      # the kernel's order
+        dsum[row0:] = _tail_sum(Ct).float()                    # the kernel's order: parts in fp32, one rounding
         xn = x + dsum
         if two:
             e2 = d2.float()
-            e2[row0:] = e2[row0:] + d2t[0].float()
+            e2[row0:] = _tail_sum(d2t).float()
             xn = xn + e2
         assert torch.equal(xx, xn)
         assert gu.rel_err(y, F.layer_norm(xn, (N,), eps=1e-6) * (sc + 1) + sh) < 1e-2

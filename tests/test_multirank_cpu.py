@@ -3,6 +3,7 @@ code with backend nccl = RCCL).  Covers the one collective (flat weight broadcas
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -117,3 +118,30 @@ def test_configs3_units_shard_evenly_over_8_ranks():
     assert max(sum(frames[u] for u in s) for s in shards) <= row_cap
     # the same plan on every rank: sharding is a pure function of the seeded list
     assert sharding.shard_units(costs, 8) == shards
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` with no launcher (the form the driver uses for N = 1) must start N ranks itself -- a child
+    `python -m torch.distributed.run` on 127.0.0.1 -- instead of running one rank labelled --gpus N.  Without a GPU every rank refuses
+    loudly (the hot path has no CPU fallback), which is exactly what shows here: TWO refusals, a non-zero exit code handed through, and
+    no JSON line.  The same call on the GPU box (gloo rehearsal, n_gpus == 2 in the line) is tests/test_engine_gpu.py's two-rank test."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher; the GPU box runs the real two-rank case")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VV_BENCH_DIST_BACKEND"] = "gloo"            # (with the default nccl backend the parent already refuses: fewer cards than --gpus)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny", "--steps", "1", "--warmup", "0", "--batch", "4"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a HIP device") == 2, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    env.pop("VV_BENCH_DIST_BACKEND")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode != 0 and "HIP device(s) are visible" in r.stderr
+    # a launcher's WORLD_SIZE that disagrees with --gpus is refused before anything runs
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spec", "tiny"], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "must agree" in r.stderr

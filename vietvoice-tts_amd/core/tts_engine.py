@@ -51,6 +51,9 @@ class TTSEngine:
         self._last_plan = []
 
     def cleanup(self) -> None:
+        if self._decode_graphs is not None:       # captured graphs point into the context about to be destroyed, and pin HBM
+            self._decode_graphs.clear()
+            self._decode_graphs = None
         if self.model_session_manager:
             self.model_session_manager.cleanup()
 

@@ -456,7 +456,7 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
     nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * n_tab);
     nd.add(4ull * R * 64); nd.add(4ull * R * 64);
-    nd.add(es * tail_rows * D * (tp_o > 1 ? tp_o - 1 : 0)); nd.add(es * tail_rows * D * (tp_f > 1 ? tp_f - 1 : 0));
+    nd.add(4 * tail_rows * D * (tp_o > 1 ? tp_o : 0)); nd.add(4 * tail_rows * D * (tp_f > 1 ? tp_f : 0));
     if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
@@ -473,8 +473,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     int* tab = carve<int>(c, n_tab);
     float* csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
     float* csk_rows = carve<float>(c, R * 64);
-    char* h2_tail = carve<char>(c, es * tail_rows * D * (tp_o > 1 ? tp_o - 1 : 0));     // [parts - 1][tail_rows][D] partial deltas
-    char* h3_tail = carve<char>(c, es * tail_rows * D * (tp_f > 1 ? tp_f - 1 : 0));
+    float* h2_tail = carve<float>(c, tail_rows * D * (tp_o > 1 ? tp_o : 0));     // fp32 [parts][tail_rows][D] K parts of the tail rows' deltas
+    float* h3_tail = carve<float>(c, tail_rows * D * (tp_f > 1 ? tp_f : 0));
     const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
     KCHK(c, vvk_row_tables(seq_len, B, N, (int)Rc, tab, tab + 2 * B, tab + 2 * B + Rc, st, &m__));
     const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? csq_rows : csq, c->rope_rows ? csk_rows : csk};

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         voff_v[u] = (unsigned)row * (unsigned)ld * 2u + (unsigned)D * 2u + cv * 16;      // V = K + D columns
     }
     const int tile_bytes = 64 * ld * 2;
+    // INVARIANT (the asm form is outside hipcc's memory and waitcnt bookkeeping; nothing else guards this): stage(kt + 1, buf) must be
+    // issued AFTER the barrier at the top of tile kt, and buf must be the buffer last read in tile kt - 1 -- every wave is past that
+    // barrier only when it has finished tile kt - 1's PV reads.  The loads land under the explicit vmcnt(0) + barrier at the top of
+    // tile kt + 1.  Moving the call above the barrier, or adding a third buffer, needs a new argument; the every-row headline-size test
+    // (test_attention_headline_shape_every_row) is the regression guard.
     auto stage = [&](int kt, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

@@ -7,6 +7,17 @@
 
 namespace {
 
+// fp32 -> T -> fp32, element-wise (round to nearest even: what store4<T> / the GEMM epilogue's v_cvt_pk_bf16_f32 do)
+template <typename T> __device__ __forceinline__ float4 round4_as(float4 a) {
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(4))) float f4v;
+        const f4v r = __builtin_convertvector(__builtin_convertvector((f4v){a.x, a.y, a.z, a.w}, bf16x4), f4v);
+        return make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        return a;
+    }
+}
+
 // ---------------------------------------------------------------- K4: [x += delta;] y = LN(x) * (w [+1]) + b
 // One wave per row, the row cached in registers (D <= 1024): one HBM read, one write.  When a
 // delta is given (the gated branch output of the previous GEMM) the residual add is fused here:
@@ -16,8 +27,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
                                                      int R, int D, const float* __restrict__ w,
                                                      const float* __restrict__ b, int add_one, float eps,
                                                      const Td* __restrict__ delta, int ldd, const Td* __restrict__ delta2,
-                                                     int keep_x, int tail_row0, int tp1, const Td* __restrict__ dt1, int tp2,
-                                                     const Td* __restrict__ dt2) {
+                                                     int keep_x, int tail_row0, int tp1, const float* __restrict__ dt1, int tp2,
+                                                     const float* __restrict__ dt2) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -28,39 +39,51 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, int 
     if (delta) {
         // all loads of the row first (x, delta, delta2: up to 12 independent 16-byte loads in flight), then the adds
         float4 d[4], d2[4];
+        // rows of a split-K tail (wave-uniform, a few per cent of the rows): the GEMM left the row's K parts in fp32 and did NOT
+        // write the row of the delta itself; the parts are summed here in part order and the SUM is rounded to the delta's dtype
+        // once -- the rounding a row outside the tail got in the GEMM epilogue -- so the stream sees the same kind of delta on
+        // every row, whatever the row's position in the launch.
+        const bool tl1 = tp1 > 0 && row >= tail_row0, tl2 = tp2 > 0 && row >= tail_row0;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane + i * 64;
             if (c < n4) {
                 v[i] = load4_nt<float>(xr + c * 4);             // the fp32 stream is far larger than the caches: stream it
-                d[i] = load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
-                d2[i] = delta2 ? load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[i] = tl1 ? z4 : load4_nt<Td>(delta + (size_t)row * ldd + c * 4);      // read once: keep it out of the caches
+                d2[i] = (delta2 && !tl2) ? load4_nt<Td>(delta2 + (size_t)row * ldd + c * 4) : z4;
             } else {
-                v[i] = d[i] = d2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[i] = d[i] = d2[i] = z4;
             }
         }
         if (row >= tail_row0) {
-            // rows of a split-K tail (wave-uniform, a few per cent of the rows): the other K parts of each delta join it
-            // first, in part order, so the stream sees one delta per branch as in the rows outside the tail
             const size_t tr = (size_t)(R - tail_row0), r = (size_t)(row - tail_row0);
-            for (int p = 0; p + 1 < tp1; ++p)
+            if (tl1) {
+                for (int p = 0; p < tp1; ++p)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = lane + i * 64;
-                    if (c < n4) {
-                        const float4 t = load4_nt<Td>(dt1 + (p * tr + r) * ldd + c * 4);
-                        d[i].x += t.x; d[i].y += t.y; d[i].z += t.z; d[i].w += t.w;
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = lane + i * 64;
+                        if (c < n4) {
+                            const float4 t = load4_nt<float>(dt1 + (p * tr + r) * ldd + c * 4);
+                            d[i].x += t.x; d[i].y += t.y; d[i].z += t.z; d[i].w += t.w;
+                        }
                     }
-                }
-            for (int p = 0; p + 1 < tp2; ++p)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = lane + i * 64;
-                    if (c < n4) {
-                        const float4 t = load4_nt<Td>(dt2 + (p * tr + r) * ldd + c * 4);
-                        d2[i].x += t.x; d2[i].y += t.y; d2[i].z += t.z; d2[i].w += t.w;
+                for (int i = 0; i < 4; ++i) d[i] = round4_as<Td>(d[i]);
+            }
+            if (tl2) {
+                for (int p = 0; p < tp2; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = lane + i * 64;
+                        if (c < n4) {
+                            const float4 t = load4_nt<float>(dt2 + (p * tr + r) * ldd + c * 4);
+                            d2[i].x += t.x; d2[i].y += t.y; d2[i].z += t.z; d2[i].w += t.w;
+                        }
                     }
-                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2[i] = round4_as<Td>(d2[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -308,7 +331,9 @@ __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__
                                                          int* __restrict__ row_src, int* __restrict__ row_pos) {
     // The table sizes (Rc, 2 Rc) and every launch shape come from the HOST copy of the lengths; the device copy is clamped to
     // [0, N] and to the Rc rows that exist, so a device array that disagrees with the host one (stale tensor, wrong batch) cannot
-    // write past the tables -- it produces wrong audio for that call, never a stray store.
+    // write past the tables -- it produces wrong audio for that call, never a stray store: when the device lengths sum to FEWER
+    // rows than the host's Rc, the last workgroup fills the rows nobody owns with a valid row (source row 0, position 0), so the
+    // gathers and the read-modify-write of cfg_euler through row_src never see an unwritten index.
     const int b = blockIdx.x;
     int r0 = 0;
     for (int i = 0; i < b; ++i) r0 += min(max(seq_len[i], 0), N);   // B is at most a few hundred: a serial prefix per workgroup is cheaper than a scan
@@ -320,6 +345,12 @@ __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__
         row_pos[r0 + t] = t;
         row_pos[Rc + r0 + t] = t;
     }
+    if (b == B - 1)
+        for (int t = r0 + len + (int)threadIdx.x; t < Rc; t += 256) {
+            row_src[t] = 0;
+            row_pos[t] = 0;
+            row_pos[Rc + t] = 0;
+        }
 }
 
 // ---------------------------------------------------------------- K5: GroupNorm over channel-major slabs [B][C][T]
@@ -425,12 +456,13 @@ int vvk_ln_mod(const vv_ln_args* a, hipStream_t st, const char** err) {
     float* x = const_cast<float*>(a->x);
     const bool ob = a->out_dtype == VV_BF16, db = a->delta_dtype == VV_BF16;
     const int tp1 = a->delta && a->delta_tail_parts > 1 ? a->delta_tail_parts : 0, tp2 = a->delta2 && a->delta2_tail_parts > 1 ? a->delta2_tail_parts : 0;
+    if ((tp1 || tp2) && (((uintptr_t)a->delta_tail | (uintptr_t)a->delta2_tail) % 16)) { *err = "ln: split-K tail buffers must be 16-byte aligned"; return -22; }
     if ((a->delta_tail_parts > 1 && !a->delta) || (a->delta2_tail_parts > 1 && !a->delta2)) { *err = "ln: a delta tail without its delta"; return -22; }
     if ((tp1 || tp2) && (a->tail_row0 < 0 || a->tail_row0 >= a->R || (tp1 && !a->delta_tail) || (tp2 && !a->delta2_tail) || tp1 > 8 || tp2 > 8)) {
         *err = "ln: bad split-K tail (row0 within [0, R), buffers given, at most 8 parts)"; return -22;
     }
     const int tail_row0 = (tp1 || tp2) ? a->tail_row0 : a->R;
-#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta, (const Td*)a->delta2, a->keep_x, tail_row0, tp1, (const Td*)a->delta_tail, tp2, (const Td*)a->delta2_tail)
+#define LN_GO(To, Td) ln_mod_kernel<To, Td><<<grid, 256, 0, st>>>(x, a->ldx, (To*)a->y, a->ldy, a->R, a->D, a->w, a->b, a->add_one, a->eps, (const Td*)a->delta, a->ld_delta, (const Td*)a->delta2, a->keep_x, tail_row0, tp1, (const float*)a->delta_tail, tp2, (const float*)a->delta2_tail)
     if (ob && db) LN_GO(bf16, bf16);
     else if (ob) LN_GO(bf16, float);
     else if (db) LN_GO(float, bf16);

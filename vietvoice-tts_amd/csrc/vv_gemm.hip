@@ -49,7 +49,7 @@ struct EpiArgs {
     const int* pos_tab;      // optional: rope position of row m (packed ragged rows); default m % seq_n
     int ks;                  // split-K tail of the persistent gate-store kernel (tail_plan): K parts of the tail tiles, 1 = no tail
     int tail_panel0;         // ks > 1: first 256-row panel of the tail (a multiple of 8)
-    char* c_part;            // ks > 1: [ks - 1][M - 256 * tail_panel0][ldc] products of K parts 1.. for the tail rows (part 0 goes to C)
+    char* c_part;            // ks > 1: fp32 [ks][M - 256 * tail_panel0][ldc] gated products of the K parts of the tail rows (C's tail rows stay unwritten)
     unsigned seq_rcp;        // ceil(2^32 / seq_n): row -> position without a table when every sequence has seq_n rows (m * seq_n < 2^32)
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
@@ -544,17 +544,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
         const bool last = it + 1 == n_my;
         entry(last ? it : it + 1, bm_n, bn_n, part_n, nk_n);
         const int kb = part * nk, kb_n = part_n * nk_n;
-        // K parts 1.. write to the partial buffer [ks - 1][M - row0][ldc] (the consumer adds the parts: vv_layernorm's delta
-        // tails).  The resource base is moved back by row0 rows so that the same global-row offsets address it; only rows
-        // >= row0 are ever stored through it.
-        __amdgpu_buffer_rsrc_t rs_p = rs_c;
-        if constexpr (MODE == MODE_GATE_STORE) {
-            if (part > 0) {
-                const long long row0 = (long long)mt_main * 256;
-                rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(e.c_part + ((long long)(part - 1) * (M - row0) - row0) * ldc * (long long)sizeof(To)), 0,
-                                                         (int)min((size_t)M * ldc * sizeof(To), (size_t)0x7fffffff), 0x00020000);
-            }
-        }
+        // Tail entries (ks > 1): EVERY K part of a tail tile, part 0 included, goes to the fp32 partial buffer
+        // [ks][M - row0][ldc] and the tail rows of C stay unwritten.  The consumer (vv_layernorm's delta tails) sums the parts
+        // in fp32 and rounds the SUM to the operand dtype once -- where a row outside the tail is rounded in this epilogue -- so
+        // a tail row differs from a row outside the tail by fp32 summation order only: a row's result does not depend on
+        // where it sits in the launch (round 4; the round-2 form stored bf16-rounded parts: 24 LSB of PCM between batchings).
+        const bool tail_entry = MODE == MODE_GATE_STORE && ks > 1 && it >= n_my_main;
         // accumulators start at the bias (feature-only), so the epilogue has no bias pass
         const float bias_cur = part == 0 ? bias_nx : 0.f;          // the bias belongs to K part 0 only
 #pragma unroll
@@ -648,6 +643,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         }
                 }
         }
+        if (tail_entry) {
+            if constexpr (MODE == MODE_GATE_STORE && G1) {
+                // fp32 parts straight from the accumulators: a lane holds 4 consecutive features of a token (16 bytes), the 4 cq lanes of
+                // a token make one 64-byte segment.  32 stores per wave instead of 16: every counted wait behind them only waits longer.
+                const int row0 = mt_main * 256, tail_rows = M - row0;
+                const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(e.c_part + (size_t)part * tail_rows * ldc * 4), 0, (int)min((size_t)tail_rows * ldc * 4, (size_t)0x7fffffff), 0x00020000);
+                if (e.bias) bias_nx = load_async(e.bias + bn_n + wc * 64 + lane);
+                gate_nx = load_async(e.gate + bn_n + wc * 64 + lane);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int mrow = bm - row0 + g * 128 + mh * 64 + mi * 16 + r16;
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                                const u32x4 vv = __builtin_bit_cast(u32x4, acc[mh][nh][mi][ni]);
+                                const unsigned off = ((unsigned)mrow * (unsigned)ldc + (unsigned)(bn + wc * 64 + nh * 32 + ni * 16 + cq * 4)) * 4u;
+                                __builtin_amdgcn_raw_buffer_store_b128(vv, rs_f, (int)(mrow < tail_rows ? off : 0x7ffffff0u), 0, 2);
+                            }
+                    }
+                asm volatile("s_waitcnt vmcnt(32)" : "+v"(bias_nx), "+v"(gate_nx)::"memory");
+            }
+        } else
         if constexpr (sizeof(To) == 2 && MODE != MODE_GATE_RES) {
             // bf16 output: transpose through a wave-private 4 KiB LDS region (32 tokens x 64 features per pass, 16-byte
             // chunk index XOR (row & 7)) so that global stores are whole 128-byte rows.  The unit slots are NOT
@@ -733,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         const int row_first = bm + g * 128 + ps * 32 + q * 8;                  // wave-uniform
                         const bool ok = (lane >> 3) < M - row_first && n0 < e.n_store;
                         const unsigned soff = ((unsigned)row_first * (unsigned)ldc + (unsigned)(bn + wc * 64)) * 2u;
-                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_p, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
+                        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_c, (int)(ok ? st_lane : 0x7ffffff0u), (int)soff, 2);   // nt; dropped when out of range
                     } else
                     if (m < M && n0 < e.n_store) {   // streamed once, read by the next kernel from HBM anyway
                         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -820,8 +842,8 @@ struct KernelSetup {
 // Split-K tail of the persistent kernel.  One workgroup per CU walks ceil(tiles / n_cu) tiles, so a tile count that is not a
 // multiple of n_cu pays a whole round for the remainder (the flagship's 1600 tiles of the two N = 1024 GEMMs: 6.25 rounds of
 // work in 7).  The plan cuts the row panels into a main part that fills whole rounds and a tail whose tiles are split `parts`
-// ways along K so that tail_tiles * parts entries fill (at most) one more, 1/parts as long, round.  Part 0 lands in C as
-// always; parts 1.. land in a partial buffer [parts - 1][M - row0][ldc] which the consumer adds (vv_ln_args.delta_tail).
+// ways along K so that tail_tiles * parts entries fill (at most) one more, 1/parts as long, round.  Every part of a tail row
+// lands in an fp32 partial buffer [parts][M - row0][ldc]; the consumer sums them and rounds once (vv_ln_args.delta_tail).
 // Returns parts = 0 when there is nothing to gain (no remainder, remainder too large, K too short).
 // The persistent kernel addresses its operands through buffer resources with a 31-bit num_records: operands of 2 GiB or more
 // take the plain-pointer kernels (64-bit addressing) instead.  The split-K tail exists in the persistent kernel only, so the
@@ -936,6 +958,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         if (parts != g->tail_parts || row0 != g->tail_row0 || !g->C_tail || ((uintptr_t)g->C_tail % 16)) {
             *err = "gemm: split-K tail does not match vv_gemm_tail_plan for this shape"; return -22;
         }
+        if ((size_t)(g->M - row0) * g->ldc * 4 >= ((size_t)1 << 31)) { *err = "gemm: split-K tail buffer of 2 GiB or more"; return -22; }
         e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
     }
     e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;

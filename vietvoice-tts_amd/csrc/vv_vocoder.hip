@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 4) void conv_mfma_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-    const int lin = len_in ? min(len_in[b], T_in) : T_in;
+    const int lin = len_in ? max(0, min(len_in[b], T_in)) : T_in;
     const float* inb = in + (size_t)b * Cin * T_in;
     const bool vec_ok = (T_in & 3) == 0 && ((uintptr_t)in & 15) == 0;
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void mrf_pair_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
-    const int lin = len_in ? min(len_in[b], T) : T;
+    const int lin = len_in ? max(0, min(len_in[b], T)) : T;
     const float* yb = y + (size_t)b * C * T;
     const bool vec_ok = (T & 3) == 0 && ((uintptr_t)y & 15) == 0;
 
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t = (blockIdx.x * 4 + wave) * POST_WAVE_OUT + (lane - 1) * 4;       // first of this lane's 4 samples (lane 0: the left halo)
-    const int lin = len_in ? min(len_in[b], T) : T;
+    const int lin = len_in ? max(0, min(len_in[b], T)) : T;
     const float* row = in + (size_t)b * C * T;
     // a float4 that straddles the valid length is cut per element (the range check of a 16-byte load is not relied on for that)
     const bool m1 = t + 1 < lin, m2 = t + 2 < lin, m3 = t + 3 < lin;
