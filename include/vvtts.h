@@ -89,6 +89,16 @@ VV_API int vv_preprocess(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld
                   const int32_t* seq_len, float* cat_mel_text, float* cat_mel_text_drop,
                   int32_t* ref_signal_len, void* stream);
 
+/* The same call with the clip lengths also handed over on the HOST (same values as the device array).  A centred STFT reflects
+ * n_fft / 2 samples at both ends of a clip, which is defined only for clips of more than n_fft / 2 samples (the reference admits
+ * any clip, core/audio_processor.py:15-26, core/tts_engine.py:46-56; torch.stft refuses a shorter one): this form returns -22
+ * for such an item before anything is launched.  Without host lengths (vv_preprocess) the mel kernel clamps the doubly reflected
+ * index -- finite, deterministic, defined by no reference. */
+VV_API int vv_preprocess_h(vv_ctx* ctx, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len,
+                    const int32_t* audio_len, const int32_t* audio_len_host, const int32_t* text_ids, int ld_text,
+                    const int32_t* text_len, const int32_t* seq_len, float* cat_mel_text, float* cat_mel_text_drop,
+                    int32_t* ref_signal_len, void* stream);
+
 /* replaces the loop over sessions['transformer'].run, core/tts_engine.py:148-174: n_steps Euler
  * steps of the flow ODE starting at step index step0, state x [B][N][n_mel] f32 updated in HBM.
  * rope tables are [>=N][head_dim] f32 (q tables carry the softmax scale). */
@@ -123,11 +133,11 @@ VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the co
 /* Context switches (explicit API, never the environment).  "fuse_mrf": run the MRF resblock pairs of the C <= 64 vocoder
  * stages through vv_mrf_resblock's fused kernel -- 0 never (two vv_conv1d launches per pair), 1 always, 2 (default) for
  * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way.
- * "split_k_tail" (bf16 acoustic model): lets vv_transformer_steps take vv_gemm_tail_plan's split-K tail -- 0 never, 1 for the
- * out-projection and FF2 GEMMs, 2 (default) for FF2 only (the measured optimum at the flagship shape: the parts cost the
- * consuming norms extra reads).  The K parts of a tail row are kept in fp32, summed by the consuming norm and the SUM rounded to
- * bf16 once, where a row outside the tail is rounded in the GEMM epilogue: a tail row differs from the plain launch by fp32
- * summation order only (a row's result does not depend on its position in the launch); the fp32 path never splits.
+ * "split_k_tail" (bf16 acoustic model): lets vv_transformer_steps take vv_gemm_tail_plan's split-K tail -- 0 (default) never,
+ * 1 for the out-projection and FF2 GEMMs, 2 for FF2 only.  The K parts of a tail row are kept in fp32, summed by the consuming
+ * norm and the SUM rounded to bf16 once, where a row outside the tail is rounded in the GEMM epilogue: a tail row differs from
+ * the plain launch by fp32 summation order -- which later bf16 roundings amplify to bf16-level noise, so with the tail on a row's
+ * result depends (inside the bf16 tolerance class) on its position in the launch.  Off, it does not; the fp32 path never splits.
  * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 

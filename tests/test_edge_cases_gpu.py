@@ -117,3 +117,93 @@ def test_abi_argument_errors_are_codes_not_aborts(hip_tiny, tiny_setup):
     # the context is still usable
     y = gu.gemm(eng, torch.ones(64, 64, device=DEV), torch.ones(128, 64, device=DEV))
     assert float(y.min()) == float(y.max()) == 64.0
+
+
+def test_short_reference_clip_is_refused_with_host_lengths(hip_tiny, tiny_setup):
+    """a reference clip of n_fft / 2 samples or fewer has no defined centred STFT (torch.stft refuses it; the reference
+    admits any clip, /root/reference/vietvoicetts/core/audio_processor.py:15-26, core/tts_engine.py:46-56).  With the clip lengths on
+    the host (vv_preprocess_h) the call returns -22 naming the item BEFORE anything is launched -- also when the short item sits beside
+    a long one, the case that used to be silently double-reflected -- and the context keeps working; the device-only form stays finite."""
+    spec, w, _ = tiny_setup
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(8)
+    short = spec.n_fft // 2                                   # one sample too few
+    la, lt, gen = [256 * 10, short], [12, 9], [6, 4]
+    seq = [la[b] // spec.hop_length + 1 + gen[b] for b in range(2)]
+    N = max(seq)
+    audio = torch.zeros(2, max(la), dtype=torch.int16)
+    for b in range(2):
+        audio[b, : la[b]] = (torch.randn(la[b], generator=g) * 3000).to(torch.int16)
+    ids = torch.randint(1, spec.vocab_size, (2, max(lt)), generator=g, dtype=torch.int32)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    args = (audio.to(DEV), i32(la), ids.to(DEV), i32(lt), i32(seq), N)
+    with pytest.raises(RuntimeError, match=r"reference clip 1 has %d samples" % short):
+        eng.preprocess(*args, audio_len_host=la)
+    with pytest.raises(RuntimeError, match="reference clip 0 has"):       # a host length beyond max_audio_len is a caller bug too
+        eng.preprocess(*args, audio_len_host=[max(la) + 1, 600])
+    ok = eng.preprocess(*args)                                # device-only lengths: defined by the kernel's clamp (finite, deterministic)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ok["cat_mel_text"]).all())
+    la2 = [la[0], short + 1]                                  # the smallest admitted clip
+    ok2 = eng.preprocess(audio.to(DEV), i32(la2), ids.to(DEV), i32(lt), i32(seq), N, audio_len_host=la2)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ok2["cat_mel_text"]).all()) and int(ok2["ref_signal_len"][1]) == la2[1] // spec.hop_length + 1
+
+
+def test_device_lengths_shorter_than_host_lengths_leave_no_stray_index(hip_tiny, tiny_setup):
+    """the launch shapes come from the HOST copy of the lengths; a device copy that sums to FEWER rows used to leave
+    row_src / row_pos of the missing rows unwritten (arena memory), and cfg_euler / pack_cat gather and scatter through them.  The last
+    workgroup of row_tables_kernel now maps those rows onto padding rows of the last item.  A larger call runs first, so that the table
+    offsets of the mismatched call hold activation bit patterns (huge as indices) rather than a previous call's valid tables.  Checked:
+    the call returns, the state stays finite, and item 0 -- whose lengths agree -- equals the matched run bit for bit."""
+    spec, w, _ = tiny_setup
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(21)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
+
+    def inputs(la, lt, gen):
+        seq = [la[b] // spec.hop_length + 1 + gen[b] for b in range(len(la))]
+        audio = torch.zeros(len(la), max(la), dtype=torch.int16)
+        for b in range(len(la)):
+            audio[b, : la[b]] = (torch.randn(la[b], generator=g) * 3000).to(torch.int16)
+        ids = torch.randint(1, spec.vocab_size, (len(la), max(lt)), generator=g, dtype=torch.int32)
+        return audio, ids, seq, torch.randn(len(la), max(seq), spec.n_mel, generator=g)
+
+    la, lt = [256 * 8, 256 * 6], [10, 7]
+    audio, ids, seq_host, noise = inputs(la, lt, [9, 7])
+    seq_dev = [seq_host[0], seq_host[1] - 5]                 # the device array claims fewer rows for the LAST item
+    N = max(seq_host)
+    pre = eng.preprocess(audio.to(DEV), i32(la), ids.to(DEV), i32(lt), i32(seq_host), N, seq_len_host=seq_host)
+    x_ok = noise.to(DEV).clone()
+    eng.transformer_steps(x_ok, pre, 0, 2)
+    # a larger call: the arena region where the next call's tables will sit now holds activations
+    lb, ltb = [256 * 20, 256 * 18, 256 * 16], [20, 18, 16]
+    ab, ib, sb, nb = inputs(lb, ltb, [30, 28, 26])
+    pre_b = eng.preprocess(ab.to(DEV), i32(lb), ib.to(DEV), i32(ltb), i32(sb), max(sb), seq_len_host=sb)
+    eng.transformer_steps(nb.to(DEV).clone(), pre_b, 0, 1)
+    pre_bad = dict(pre, seq_len=i32(seq_dev))
+    x_bad = noise.to(DEV).clone()
+    eng.transformer_steps(x_bad, pre_bad, 0, 2, seq_len_host=seq_host)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(x_bad).all())
+    assert torch.equal(x_bad[0, : seq_host[0]], x_ok[0, : seq_host[0]])            # item 0 is untouched by item 1's mismatch
+
+
+def test_conv_post_negative_length_is_an_empty_row(hip_tiny):
+    """a negative len_in (reachable through the exported vv_conv_post) is an empty row, not a 4 GiB buffer resource."""
+    from tests import gpu_util as gu
+    eng = hip_tiny["f32"]
+    B, Cc, T = 2, 8, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Cc, T, generator=g)
+    wgt = torch.randn(Cc, 7, generator=g) * 0.1
+    pcm = torch.full((B, T), 77, dtype=torch.int16, device=DEV)
+    wave = torch.full((B, T), 9.0, device=DEV)
+    dl = torch.tensor([-5, T], dtype=torch.int32, device=DEV)
+    bias = 0.25
+    gu.check(eng, eng.lib.vv_conv_post(eng.ctx, x.to(DEV).data_ptr(), wgt.to(DEV).data_ptr(), bias, pcm.data_ptr(), T, wave.data_ptr(), B, Cc, T, 7, 0.01,
+                                       dl.data_ptr(), gu.stream()))
+    torch.cuda.synchronize()
+    assert float((wave[0] - math.tanh(bias)).abs().max()) < 1e-6        # every input sample of the empty row reads as zero: tanh(bias)
+    ref1 = torch.tanh(F.conv1d(F.leaky_relu(x[1:2], 0.01), wgt.reshape(1, Cc, 7), torch.tensor([bias]), padding=3)).reshape(T)
+    assert float((wave[1].cpu() - ref1).abs().max()) < 2e-6

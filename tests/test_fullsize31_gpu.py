@@ -131,10 +131,11 @@ def test_bf16_production_run_close_to_the_oracle_fixture(gold):
 
 
 def test_bf16_headline_batch_item0_production_run(gold):
-    """configs[2] itself: the headline batch (B = 32, bench inputs, bf16 acoustic + fp32-fidelity vocoder, the split-K tail on) through
+    """configs[2] itself: the headline batch (B = 32, bench inputs, bf16 acoustic + fp32-fidelity vocoder) through
     `synthesize_batch` -- the call bench.py times -- with the production step count; item 0 of the batch against the oracle fixture
     (same bounds as the single-utterance run: rows are packed and every kernel is row- or sequence-local), the whole batch finite,
-    full length and not one utterance repeated."""
+    full length and not one utterance repeated; then item 31 -- the last rows of every launch -- against its own fixture, with and
+    without the split-K tail option."""
     import bench
     from vietvoice_tts_amd.runtime import HipSynth
     g = gold
@@ -152,15 +153,46 @@ def test_bf16_headline_batch_item0_production_run(gold):
     ref_pcm = torch.from_numpy(g["arr"]["pcm"]).double()
     pr = float((pcm[0, :n].cpu().double() - ref_pcm).pow(2).mean().sqrt() / ref_pcm.pow(2).mean().sqrt())
     print(f"\n[full bf16 B=32, 31 steps] item 0 vs the float64 fixture: state rmse/rms {rm:.3e}, PCM rmse/rms {pr:.3e}")
-    assert rm <= 2.0 * BF16_MEASURED[31] and pr <= 2.0 * BF16_MEASURED["wave"]
+    assert rm <= 2.0 * BF16_MEASURED[31] and pr <= 2.0 * BF16_MEASURED["pcm"]
     assert float((x[1] - x[0]).abs().max()) > 1e-2 and float(pcm.float().abs().amax(dim=1).min()) > 0
+    # ---- item 31, the LAST item of the batch: its unconditional rows are the last rows of every launch (rows 100,800 .. 102,399 of
+    # 102,400: the last row panels of the persistent GEMM, the panels a split-K tail would take), against ITS OWN float64 fixture
+    # (tests/golden/fullsize_golden_item31.*, generator `make_fullsize_golden.py --item 31`): every item is an independent B = 1 call
+    # in the reference (/root/reference/vietvoicetts/core/tts_engine.py:47,121), so the last item is held to the first one's bounds.
+    with open(os.path.join(GOLD, "fullsize_golden_item31.json")) as fh:
+        m31 = json.load(fh)
+    a31 = np.load(os.path.join(GOLD, "fullsize_golden_item31.npz"))
+    assert m31["item"] == 31 and m31["truth"] == "f64" and m31["nfe_step"] == 32
+    assert _digest(g["d"]["audio"][31]) == m31["inputs"]["audio0"] and _digest(g["d"]["ids"][31]) == m31["inputs"]["ids0"]
+    assert _digest(g["d"]["noise"][31]) == m31["inputs"]["noise0"]
+    ref31 = torch.from_numpy(a31["x31"]).double()
+    rm31 = float((x[31].cpu().double() - ref31).pow(2).mean().sqrt() / ref31.pow(2).mean().sqrt())
+    rp31 = torch.from_numpy(a31["pcm"]).double()
+    pr31 = float((pcm[31, :n].cpu().double() - rp31).pow(2).mean().sqrt() / rp31.pow(2).mean().sqrt())
+    print(f"[full bf16 B=32, 31 steps] item 31 (last rows of every launch) vs its float64 fixture: state rmse/rms {rm31:.3e}, PCM rmse/rms {pr31:.3e}")
+    assert rm31 <= 2.0 * BF16_MEASURED[31] and pr31 <= 2.0 * BF16_MEASURED["pcm"]
+    # ---- the same item with the split-K tail OPTION on (FF2): its unconditional rows then really are tail rows (K parts summed by the
+    # LayerNorm) -- the tail's arithmetic against the oracle, not only against the plain launch
+    eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
+    eng.set_option("split_k_tail", 2)
+    xt, pcmt, _lt, _p = eng.synthesize_batch(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], g["N"], d["noise"], bench.GEN_FRAMES,
+                                             seq_len_host=d["seq_len_host"])
+    torch.cuda.synchronize()
+    eng.close()
+    rmt = float((xt[31].cpu().double() - ref31).pow(2).mean().sqrt() / ref31.pow(2).mean().sqrt())
+    prt = float((pcmt[31, :n].cpu().double() - rp31).pow(2).mean().sqrt() / rp31.pow(2).mean().sqrt())
+    print(f"[full bf16 B=32, 31 steps] item 31 with split_k_tail = 2: state rmse/rms {rmt:.3e}, PCM rmse/rms {prt:.3e}; item 0 unchanged: {bool(torch.equal(xt[0], x[0]))}")
+    assert rmt <= 2.0 * BF16_MEASURED[31] and prt <= 2.0 * BF16_MEASURED["pcm"]
+    assert torch.equal(xt[0], x[0]) and not torch.equal(xt[31], x[31])       # item 0 never enters a tail; item 31 does
 
 
-def test_fp32_ragged_batch_production_run():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_ragged_batch_production_run(dtype):
     """BASELINE configs[3] semantics with the production step count at FULL size: three utterances of different reference-clip, text
     and frame lengths as ONE packed ragged batch (per-item masks in attention / pos-conv / text conv, packed GEMM rows, bucketed
-    vocoder), fp32, all 31 steps; items 1 and 2 against the float64 oracle run on each item ALONE
-    (tests/golden/fullsize_ragged_golden.*, generator `make_fullsize_golden.py --ragged`), bounds from the torch-fp32 yardstick."""
+    vocoder), all 31 steps; EVERY item (0: 1600 frames at row_start 0, 1: 851, 2: 411) against the float64 oracle run on that item
+    ALONE (tests/golden/fullsize_ragged_golden.*, generator `make_fullsize_golden.py --ragged [--items 0]`).  fp32: bounds from the
+    torch-fp32 yardstick in the fixture; bf16 (configs[3]'s arithmetic): 2 x the figures measured when the case was added (round 4)."""
     import importlib.util
     import bench  # noqa: F401  (the generator module imports it)
     from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
@@ -177,7 +209,7 @@ def test_fp32_ragged_batch_production_run():
     assert seq == meta["seq"] and _digest(audio) == meta["inputs"]["audio"] and _digest(ids) == meta["inputs"]["ids"] and _digest(noise) == meta["inputs"]["noise"]
     la, lt, gf = meta["la"], meta["lt"], meta["gf"]
     N = max(seq)
-    eng = HipSynth(spec, w, acoustic_dtype="fp32", nfe_step=32)
+    eng = HipSynth(spec, w, acoustic_dtype=dtype, nfe_step=32)
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=DEV)
     pre = eng.preprocess(audio.to(DEV), i32(la), ids.to(DEV), i32(lt), i32(seq), N, seq_len_host=seq)
     x = noise.to(DEV).clone()
@@ -186,7 +218,8 @@ def test_fp32_ragged_batch_production_run():
     torch.cuda.synchronize()
     eng.close()
     checks = []
-    for b in (1, 2):
+    assert sorted(meta["items"]) == ["0", "1", "2"]
+    for b in (0, 1, 2):
         it = meta["items"][str(b)]
         y = it["torch_fp32_vs_f64"]
         ref = torch.from_numpy(arr[f"x31_{b}"]).double()
@@ -195,9 +228,14 @@ def test_fp32_ragged_batch_production_run():
         mx, rm = float(err.max()), float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         n = arr[f"pcm_{b}"].size
         dp = (pcm[b, :n].cpu().int() - torch.from_numpy(arr[f"pcm_{b}"]).int()).abs()
-        print(f"\n[full fp32 ragged, 31 steps] item {b} (N = {seq[b]}, T = {lt[b]}, gen = {gf[b]}): HIP max|err| {mx:.2e} rmse/rms {rm:.2e} | torch-fp32 oracle "
+        rp = torch.from_numpy(arr[f"pcm_{b}"]).double()
+        pr = float((pcm[b, :n].cpu().double() - rp).pow(2).mean().sqrt() / rp.pow(2).mean().sqrt())
+        print(f"\n[full {dtype} ragged, 31 steps] item {b} (N = {seq[b]}, T = {lt[b]}, gen = {gf[b]}): HIP max|err| {mx:.2e} rmse/rms {rm:.2e} PCM rmse/rms {pr:.2e} | torch-fp32 oracle "
               f"{y['max_err']:.2e} / {y['rmse_over_rms']:.2e}; PCM max diff {int(dp.max())} LSB ({int((dp > 0).sum())} of {n} differ; torch-fp32 {y['pcm_max_lsb']} LSB)")
         assert int(pre["ref_signal_len"][b]) == it["ref_signal_len"] and int(pcm_len[b]) == n == gf[b] * spec.hop_length
+        if dtype == "bf16":
+            checks += [(f"bf16 state rmse/rms item {b}", rm, 2.0 * BF16_RAGGED_MEASURED[b][0]), (f"bf16 pcm rmse/rms item {b}", pr, 2.0 * BF16_RAGGED_MEASURED[b][1])]
+            continue
         # measured: item 1 max err 2.9e-3 (2.8 x the torch-fp32 figure, one element of a state of range 12.8) / rmse 1.25 x; item 2 1.07 x / 0.81 x
         checks += [(f"state max err item {b}", mx, 4.0 * y["max_err"] + 2e-6), (f"state rmse item {b}", rm, 2.0 * y["rmse_over_rms"] + 2e-7),
                    (f"pcm lsb item {b}", int(dp.max()), y["pcm_max_lsb"] + 1), (f"pcm share beyond 1 LSB item {b}", float((dp > 1).float().mean()), 1e-4)]
@@ -205,5 +243,8 @@ def test_fp32_ragged_batch_production_run():
     assert not bad, bad
 
 
-# state rmse/rms after steps 1, 8, 16, 24, 31 and waveform rmse/rms of the bf16 run above, as first measured (round 3)
-BF16_MEASURED = {1: 1.83e-5, 8: 9.02e-4, 16: 2.91e-3, 24: 4.49e-3, 31: 5.17e-3, "wave": 5.06e-3}
+# state rmse/rms after steps 1, 8, 16, 24, 31 and waveform rmse/rms of the bf16 run above, as first measured (round 3); "pcm" = the
+# int16 PCM's rmse/rms against the fixture's PCM (its own measured figure since round 4: the waveform's plus the quantisation)
+BF16_MEASURED = {1: 1.83e-5, 8: 9.02e-4, 16: 2.91e-3, 24: 4.49e-3, 31: 5.17e-3, "wave": 5.06e-3, "pcm": 5.2e-3}
+# bf16 ragged batch, per item (state rmse/rms after 31 steps, PCM rmse/rms): PLACEHOLDERS until measured on the GPU
+BF16_RAGGED_MEASURED = {0: (5.2e-3, 5.2e-3), 1: (5.2e-3, 5.2e-3), 2: (5.2e-3, 5.2e-3)}

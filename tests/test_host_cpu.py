@@ -469,3 +469,36 @@ def test_fullsize_fixture_inputs_are_reproducible_here():
         rmeta = json.load(fh)
     audio, rids, seq, rnoise = gen.ragged_inputs(spec)
     assert seq == rmeta["seq"] and dg(audio) == rmeta["inputs"]["audio"] and dg(rids) == rmeta["inputs"]["ids"] and dg(rnoise) == rmeta["inputs"]["noise"]
+
+
+def test_short_reference_clip_raises_before_anything_runs(cpu_engine, tmp_path):
+    """a reference clip of n_fft / 2 samples or fewer has no defined centred STFT.  The reference admits any clip
+    (/root/reference/vietvoicetts/core/audio_processor.py:15-26, core/tts_engine.py:46-56) and would fail inside the preprocess graph;
+    here `_prepare_inputs` raises ValueError in the wording of the reference's other reference-audio error (:73) before any session
+    runs, and `synthesize` wraps it like every error of the per-chunk work (:256-257)."""
+    import wave as wavmod
+    eng = cpu_engine
+    n_fft = eng.model_session_manager.spec.n_fft
+    calls = []
+    orig = eng._synthesize_sessions
+    eng._synthesize_sessions = lambda inputs: (calls.append(len(inputs)), orig(inputs))[1]
+
+    def clip(n):
+        p = str(tmp_path / f"clip{n}.wav")
+        with wavmod.open(p, "wb") as fh:
+            fh.setnchannels(1); fh.setsampwidth(2); fh.setframerate(24000)
+            fh.writeframes((np.sin(np.arange(n) * 0.05) * 9000).astype(np.int16).tobytes())
+        return p
+    with pytest.raises(ValueError, match=r"Reference audio is too short \(%d samples" % (n_fft // 2)):
+        eng._prepare_inputs(clip(n_fft // 2), "xin chào", "chào bạn")
+    c = eng.config
+    saved = (c.gender, c.group, c.area, c.emotion)
+    c.gender = c.group = c.area = c.emotion = None                  # (the config's voice filters exclude a user clip, core/model.py:153-175)
+    try:
+        with pytest.raises(RuntimeError, match="Speech synthesis failed: Reference audio is too short"):
+            eng.synthesize("chào bạn", reference_audio=clip(n_fft // 2), reference_text="xin chào")
+    finally:
+        c.gender, c.group, c.area, c.emotion = saved
+    assert calls == []                                              # nothing was launched
+    assert len(eng._prepare_inputs(clip(n_fft // 2 + 1), "xin chào", "chào bạn")) == 1      # the smallest admitted clip
+    eng._synthesize_sessions = orig

@@ -7,10 +7,11 @@ Checked: the chunk count is the plan's; the buffered result (`synthesize`) with 
 engine on the same seed; `synthesize_stream` with the same 8-chunk groups equals the buffered result; the second call on one
 engine replays the cached graph (hit, no new capture).  bf16 acoustic: the chunks of one text are grouped by length in the
 buffered call and in text order in the streamed one, i.e. a chunk shares its GEMM launches with different neighbours.  Rows are
-packed and every kernel is row- or sequence-local, so with the split-K tail of the FF2 GEMM off (the one place where a row's
-arithmetic depends on its position in the launch: tail rows sum four bf16-rounded K parts) streamed and buffered audio are equal
-to the cross-fade's LSB; with the default tail they agree in the bf16 tolerance class (measured 3.4e-4 rmse / rms, 24 LSB max on
-a +-20,000 LSB signal; bounds = 3 x).
+packed and every kernel is row- or sequence-local, so streamed and buffered audio are equal to the cross-fade's LSB (measured 0):
+a chunk's audio does not depend on what shares its launch.  The one exception is an OPTION, off by default since round 4: the
+split-K tail of the FF2 GEMM (tail rows sum fp32 K parts in another order than the MFMA accumulator; the next bf16 rounding
+turns that into bf16-level noise: measured 22 LSB max / 3.4e-4 rmse / rms on a +-20,000 LSB signal with the parts in fp32, 24 LSB
+with the round-3 bf16 parts) -- checked here as the option's documented tolerance class.
 """
 import numpy as np
 import pytest
@@ -76,15 +77,15 @@ def test_longform_4k_chars_batch8_hipgraph_vocoder(tmp_path):
     mx_e, share_e, rel_e = _diff(we, wg)
     print(f"[longform full bf16] hipGraph vocoder vs eager: max {mx_e} LSB, share beyond 1 LSB {share_e:.2e}, rmse/rms {rel_e:.2e}")
     assert mx_e <= 1 and share_e <= 1e-4
-    assert mx <= 72 and rel <= 1e-3                     # default split-K tail: bf16 tolerance class, 3 x measured
+    assert mx <= 2 and share <= 1e-4                    # default (no split-K tail): a row's arithmetic is independent of its batch neighbours
 
-    # ---- the same comparison with the position-dependent split-K tail off: every row's arithmetic is independent of its batch
-    b0 = _engine(tmp_path, split_k_tail=0, use_hip_graph=True)
-    w0, _ = b0.synthesize(TEXT)
-    b0.cleanup()
-    s0 = _engine(tmp_path, split_k_tail=0, use_hip_graph=True)
-    ws0 = np.concatenate(list(s0.synthesize_stream(TEXT, chunks_per_step=8)))
-    s0.cleanup()
-    mx0, share0, rel0 = _diff(ws0, w0)
-    print(f"[longform full bf16] split_k_tail = 0: streamed vs buffered max {mx0} LSB, share beyond 1 LSB {share0:.2e}, rmse/rms {rel0:.2e}")
-    assert mx0 <= 2 and share0 <= 1e-4
+    # ---- the same comparison with the position-dependent split-K tail option ON (FF2): bf16 tolerance class, 3 x measured
+    b2 = _engine(tmp_path, split_k_tail=2, use_hip_graph=True)
+    w2, _ = b2.synthesize(TEXT)
+    b2.cleanup()
+    s2 = _engine(tmp_path, split_k_tail=2, use_hip_graph=True)
+    ws2 = np.concatenate(list(s2.synthesize_stream(TEXT, chunks_per_step=8)))
+    s2.cleanup()
+    mx2, share2, rel2 = _diff(ws2, w2)
+    print(f"[longform full bf16] split_k_tail = 2 (option): streamed vs buffered max {mx2} LSB, share beyond 1 LSB {share2:.2e}, rmse/rms {rel2:.2e}")
+    assert mx2 <= 72 and rel2 <= 1e-3

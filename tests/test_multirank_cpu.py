@@ -123,8 +123,8 @@ def test_configs3_units_shard_evenly_over_8_ranks():
 def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
     """`python bench.py --gpus N` with no launcher (the form the driver uses for N = 1) must start N ranks itself -- a child
     `python -m torch.distributed.run` on 127.0.0.1 -- instead of running one rank labelled --gpus N.  Without a GPU every rank refuses
-    loudly (the hot path has no CPU fallback), which is exactly what shows here: TWO refusals, a non-zero exit code handed through, and
-    no JSON line.  The same call on the GPU box (gloo rehearsal, n_gpus == 2 in the line) is tests/test_engine_gpu.py's two-rank test."""
+    loudly (the hot path has no CPU fallback), which is exactly what shows here: two ranks in the launcher's report, their refusals, a
+    non-zero exit code handed through, and no JSON line.  The same call on the GPU box (gloo rehearsal, n_gpus == 2 in the line) is tests/test_engine_gpu.py's two-rank test."""
     import subprocess
     import sys
     import torch
@@ -136,7 +136,9 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny", "--steps", "1", "--warmup", "0", "--batch", "4"],
                        capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a HIP device") == 2, r.stderr[-2000:]
+    # both ranks existed (the launcher's failure report names them) and refused; the launcher may end the second one before it has
+    # printed its own refusal, so the count of refusals is 1 or 2
+    assert "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr and 1 <= r.stderr.count("bench.py needs a HIP device") <= 2, r.stderr[-2000:]
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     env.pop("VV_BENCH_DIST_BACKEND")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spec", "tiny"], capture_output=True, text=True, timeout=600, cwd=root, env=env)

@@ -80,6 +80,15 @@ class TTSEngine:
         target_text = self.text_processor.clean_text(target_text)
 
         n_samples = audio.shape[-1]
+        # The reference admits any clip (core/audio_processor.py:15-26, core/tts_engine.py:46-56) and leaves a too-short one to the
+        # preprocess graph.  Its mel front end is a centred STFT, which reflects n_fft / 2 samples at both ends: defined only for
+        # clips of more than n_fft / 2 samples.  Refused here, before anything is launched, in the wording of the reference's
+        # other reference-audio error (:73); `synthesize` wraps it like every error of the per-chunk work (:256-257).
+        spec = getattr(getattr(self, "model_session_manager", None), "spec", None)
+        min_samples = (spec.n_fft // 2 + 1) if spec is not None else 1
+        if n_samples < min_samples:
+            raise ValueError(f"Reference audio is too short ({n_samples} samples, {n_samples / cfg.sample_rate:.3f}s): "
+                             f"at least {min_samples} samples ({min_samples / cfg.sample_rate:.3f}s) are needed")
         ref_frames = n_samples // cfg.hop_length + 1
         ref_seconds = n_samples / cfg.sample_rate
         ref_units = self.text_processor.calculate_text_length(reference_text, cfg.pause_punctuation)
@@ -201,7 +210,7 @@ class TTSEngine:
                 noise[i, : seq[i]] = noise_blocks[j]
             t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
             if self.config.use_hip_graph:
-                pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, seq_len_host=seq)
+                pre = eng.preprocess(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, seq_len_host=seq, audio_len_host=lens_a)
                 x = noise.to(dev)
                 eng.transformer_steps(x, pre, 0, eng.n_steps)
                 if self._decode_graphs is None:
@@ -209,7 +218,8 @@ class TTSEngine:
                 pcm, pcm_len = self._decode_graphs.get(B, N, t_gen)(x, pre["ref_signal_len"], pre["seq_len"])
             else:
                 _x, pcm, pcm_len, _pre = eng.synthesize_batch(audio, t32(lens_a), t32(ids), t32(lens_t), t32(seq), N, noise.to(dev), t_gen,
-                                                              gen_frames=[int(v) for v in (seq - ref_frames)], seq_len_host=seq)
+                                                              gen_frames=[int(v) for v in (seq - ref_frames)], seq_len_host=seq,
+                                                              audio_len_host=lens_a)
             pcm, pcm_len = pcm.cpu().numpy(), pcm_len.cpu().numpy()
             for i, j in enumerate(idx):
                 waves[j] = pcm[i, : pcm_len[i]].reshape(1, 1, -1)

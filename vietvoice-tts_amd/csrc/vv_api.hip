@@ -46,10 +46,13 @@ struct vv_ctx {
     int rope_rows = 0;                  // 1: the QKV rope epilogue reads row-gathered tables (vv_rope_rows).  Off by default: 11 % faster in a
                                         // back-to-back GEMM loop (tables stay cached), 0.9 % SLOWER inside the step, where the 52 MB of row
                                         // tables come from HBM each time while the 0.8 MB position tables stay in L2 (profiles/r02/gemm_notes.md)
-    int split_k_tail = 2;               // bf16 gate-store GEMMs: split the K range of the last row panels when the tile count leaves a partial
-                                        // last round of the persistent kernel (vv_gemm_tail_plan); the LayerNorm adds the parts.  0 off, 1 out-
-                                        // projection and FF2, 2 FF2 only (default: at the flagship shape the out-projection's K = 1024 tail saves
-                                        // 10 us of GEMM and costs as much again in the two norms that read its parts; FF2's K = 4096 tail pays)
+    int split_k_tail = 0;               // bf16 gate-store GEMMs: split the K range of the last row panels when the tile count leaves a partial
+                                        // last round of the persistent kernel (vv_gemm_tail_plan); the LayerNorm sums the fp32 parts and rounds
+                                        // once.  0 off (default), 1 out-projection and FF2, 2 FF2 only.  OFF since round 4: a tail row's fp32
+                                        // summation order differs from a plain row's, the next bf16 rounding turns that into bf16-level noise
+                                        // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
+                                        // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
+                                        // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
     int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
                                         // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
                                         // context: 1, fp32 context: 0 -- the numerics configuration stays on the f32 instruction)
@@ -341,9 +344,9 @@ int vv_set_time_grid(vv_ctx* c, const float* sinus_host, const float* dt_host, i
 }
 
 // --------------------------------------------------------------------------------- preprocess
-int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len, const int32_t* audio_len,
-                  const int32_t* text_ids, int ld_text, const int32_t* text_len, const int32_t* seq_len, float* cat,
-                  float* cat_drop, int32_t* ref_len, void* stream) {
+static int preprocess_impl(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len, const int32_t* audio_len,
+                           const int32_t* audio_len_host, const int32_t* text_ids, int ld_text, const int32_t* text_len, const int32_t* seq_len,
+                           float* cat, float* cat_drop, int32_t* ref_len, void* stream) {
     if (!c) return -22;
     if (!c->finalized) return c->fail(-1, "vv_preprocess: weights not finalized");
     if (B < 1 || N < 1 || !audio || !audio_len || !text_ids || !text_len || !seq_len || !cat || !cat_drop || !ref_len)
@@ -351,6 +354,14 @@ int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, i
     const vv_model_cfg& g = c->cfg;
     if (N > g.max_pos) return c->fail(-22, "vv_preprocess: N=%d exceeds the position tables (%d)", N, g.max_pos);
     if (max_audio_len < g.n_fft || max_audio_len > ld_audio) return c->fail(-22, "vv_preprocess: reference clips must hold >= n_fft samples and fit ld_audio");
+    // A centred STFT reflects n_fft / 2 samples at both ends of a clip: defined only for clips of more than n_fft / 2 samples (torch.stft
+    // refuses shorter ones).  The host lengths let the call refuse such an item before anything is launched; without them the mel kernel
+    // clamps the doubly reflected index (finite and deterministic, but no reference defines it).
+    if (audio_len_host)
+        for (int b = 0; b < B; ++b)
+            if (audio_len_host[b] < g.n_fft / 2 + 1 || audio_len_host[b] > max_audio_len)
+                return c->fail(-22, "vv_preprocess: reference clip %d has %d samples; a clip needs between n_fft/2 + 1 = %d and max_audio_len = %d",
+                               b, audio_len_host[b], g.n_fft / 2 + 1, max_audio_len);
     hipSetDevice(c->device);
     hipStream_t st = (hipStream_t)stream;
     const int Dt = g.text_dim, C2 = Dt * g.text_ff_mult, M = g.n_mel, es = c->esz();
@@ -401,6 +412,21 @@ int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, i
         KCHK(c, vvk_build_cat(mel, F_max, ref_len, tx, cat, cat_drop, B, N, M, Dt, st, &m__));
     }
     return 0;
+}
+
+int vv_preprocess(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len, const int32_t* audio_len,
+                  const int32_t* text_ids, int ld_text, const int32_t* text_len, const int32_t* seq_len, float* cat,
+                  float* cat_drop, int32_t* ref_len, void* stream) {
+    return preprocess_impl(c, B, N, audio, ld_audio, max_audio_len, audio_len, nullptr, text_ids, ld_text, text_len, seq_len, cat, cat_drop, ref_len, stream);
+}
+
+// Same, with the clip lengths ALSO given on the host (the same values as the device array): an item shorter than n_fft / 2 + 1 samples
+// is refused with -22 before anything is launched.
+int vv_preprocess_h(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio, int max_audio_len, const int32_t* audio_len,
+                    const int32_t* audio_len_host, const int32_t* text_ids, int ld_text, const int32_t* text_len, const int32_t* seq_len,
+                    float* cat, float* cat_drop, int32_t* ref_len, void* stream) {
+    if (c && !audio_len_host) return c->fail(-22, "vv_preprocess_h: host lengths missing");
+    return preprocess_impl(c, B, N, audio, ld_audio, max_audio_len, audio_len, audio_len_host, text_ids, ld_text, text_len, seq_len, cat, cat_drop, ref_len, stream);
 }
 
 // --------------------------------------------------------------------------- transformer steps

@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__
     // The table sizes (Rc, 2 Rc) and every launch shape come from the HOST copy of the lengths; the device copy is clamped to
     // [0, N] and to the Rc rows that exist, so a device array that disagrees with the host one (stale tensor, wrong batch) cannot
     // write past the tables -- it produces wrong audio for that call, never a stray store: when the device lengths sum to FEWER
-    // rows than the host's Rc, the last workgroup fills the rows nobody owns with a valid row (source row 0, position 0), so the
-    // gathers and the read-modify-write of cfg_euler through row_src never see an unwritten index.
+    // rows than the host's Rc, the last workgroup maps the rows nobody owns onto the PADDING rows of the last item (the rows of
+    // x / cat right after its device length, clamped to N - 1), so the gathers and the read-modify-write of cfg_euler through
+    // row_src never see an unwritten index and never touch a valid row of any item.
     const int b = blockIdx.x;
     int r0 = 0;
     for (int i = 0; i < b; ++i) r0 += min(max(seq_len[i], 0), N);   // B is at most a few hundred: a serial prefix per workgroup is cheaper than a scan
@@ -347,9 +348,10 @@ __global__ __launch_bounds__(256) void row_tables_kernel(const int* __restrict__
     }
     if (b == B - 1)
         for (int t = r0 + len + (int)threadIdx.x; t < Rc; t += 256) {
-            row_src[t] = 0;
-            row_pos[t] = 0;
-            row_pos[Rc + t] = 0;
+            const int p = min(len + (t - (r0 + len)), N - 1);
+            row_src[t] = b * N + p;
+            row_pos[t] = p;
+            row_pos[Rc + t] = p;
         }
 }
 

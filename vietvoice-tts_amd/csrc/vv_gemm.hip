@@ -69,6 +69,30 @@ __device__ __forceinline__ float epi_act(float x, int act) {
     return x;
 }
 
+// ONE arithmetic for both bf16 kernels (round 4).  A row's result must not depend on which kernel its launch took (M < 4096 takes
+// gemm_kernel, larger launches the persistent gemm_pp_kernel): the reference synthesises every unit as an independent B = 1 call
+// (core/tts_engine.py:47,121), so an item inside a batch of 32 has to equal the same item alone BIT FOR BIT.  Both kernels contract
+// K in the same order with the same MFMA instruction and start their accumulators at the bias; what is left are the epilogue
+// formulas, written here once with explicit fma / mul steps so that hipcc's contraction cannot differ between the two contexts.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// tanh-GELU / SiLU of two elements: x * sigmoid(w), sigmoid(w) = 1 / (1 + 2^(-w log2 e)), the -log2(e) folded into k1 / k3
+__device__ __forceinline__ void act_consts(int act, float& k1, float& k3) {
+    k1 = -1.4426950408889634f * (act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f);
+    k3 = -1.4426950408889634f * (act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f);
+}
+__device__ __forceinline__ f32x2_t act_pair(f32x2_t xv, float k1, float k3) {
+    const f32x2_t q = xv * xv;
+    const f32x2_t t = xv * __builtin_elementwise_fma(q, (f32x2_t){k3, k3}, (f32x2_t){k1, k1});
+    const f32x2_t d = (f32x2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    return xv * (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+// one interleaved rope pair: (a, b) -> (a c - b s, b c + a s)
+__device__ __forceinline__ void rope_pair(float& a, float& b, float c, float sn) {
+    const float na = __builtin_fmaf(a, c, -(b * sn));
+    const float nb = __builtin_fmaf(b, c, a * sn);
+    a = na; b = nb;
+}
+
 template <int MODE, typename To>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int m, int pos, int n0, float v0, float v1,
                                           float v2, float v3) {
@@ -81,11 +105,10 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
         if (n0 < 2 * e.rope_dim) {
             const bool is_k = n0 >= e.rope_dim;
             const int d = n0 & 63;
-            const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
+            const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);       // pair-duplicated tables: c.x == c.y
             const float4 s = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
-            const float o0 = v0 * c.x - v1 * s.x, o1 = v1 * c.y + v0 * s.y;
-            const float o2 = v2 * c.z - v3 * s.z, o3 = v3 * c.w + v2 * s.w;
-            v0 = o0; v1 = o1; v2 = o2; v3 = o3;
+            rope_pair(v0, v1, c.x, s.x);
+            rope_pair(v2, v3, c.z, s.z);
         }
         store4<To>(C + (size_t)m * ldc + n0, v0, v1, v2, v3);
     } else {   // MODE_GATE_RES: C is the fp32 residual stream, updated in place
@@ -93,7 +116,7 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
         float4 r = *(const float4*)x;
         if (e.gate) {
             const float4 g = *(const float4*)(e.gate + n0);
-            r.x += g.x * v0; r.y += g.y * v1; r.z += g.z * v2; r.w += g.w * v3;
+            r.x = __builtin_fmaf(g.x, v0, r.x); r.y = __builtin_fmaf(g.y, v1, r.y); r.z = __builtin_fmaf(g.z, v2, r.z); r.w = __builtin_fmaf(g.w, v3, r.w);
         } else {
             r.x += v0; r.y += v1; r.z += v2; r.w += v3;
         }
@@ -165,11 +188,15 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         // ------------------------------------------------ bf16: 4 x (MW/16) tiles of 16x16x32
         constexpr int MI = MW / 16;
         f32x4 acc[4][MI];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r16 = lane & 15, cq = lane >> 4;
+        // accumulators start at the bias (feature-only), as in the persistent kernel: the same fp32 sum, bit for bit
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + i * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = b4;
+        }
         for (int kt = 0; kt < nk; ++kt) {
             ring_step(kt);
             const char* sa = smem + (kt % NST) * STAGE_BYTES;
@@ -188,22 +215,28 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
         }
-        // ---- epilogue.  D[n_local = cq*4 + j][m_local = r16]; bias / activation hoisted out of the store loop
-        if (e.bias) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const float4 b = *(const float4*)(e.bias + bn + wc * 64 + ni * 16 + cq * 4);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) { acc[ni][mi][0] += b.x; acc[ni][mi][1] += b.y; acc[ni][mi][2] += b.z; acc[ni][mi][3] += b.w; }
-            }
-        }
+        // ---- epilogue.  D[n_local = cq*4 + j][m_local = r16]; the bias is already in the accumulators
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
+            if (e.act == VV_ACT_GELU_ERF) {              // the persistent kernel never takes erf-GELU: no second formula to agree with
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ni][mi][j] = epi_act(acc[ni][mi][j], e.act);
+                        for (int j = 0; j < 4; ++j) acc[ni][mi][j] = epi_act(acc[ni][mi][j], e.act);
+            } else {
+                float k1, k3;
+                act_consts(e.act, k1, k3);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const f32x2_t o = act_pair((f32x2_t){acc[ni][mi][j], acc[ni][mi][j + 1]}, k1, k3);
+                            acc[ni][mi][j] = o.x; acc[ni][mi][j + 1] = o.y;
+                        }
+            }
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -600,9 +633,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
 #endif
         // ---- epilogue: lane owns features n0..n0+3 of token m;  D[n_local = cq*4 + j][m_local = r16]
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {          // tanh-GELU or SiLU (erf-GELU is routed to the plain kernel)
-            // x * sigmoid(2u) == 0.5 x (1 + tanh u);  sigmoid(w) = 1 / (1 + 2^(-w log2 e)): the -log2(e) is folded into the constants
-            const float k1 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f : 1.0f);
-            const float k3 = -1.4426950408889634f * (e.act == VV_ACT_GELU_TANH ? 2.0f * 0.7978845608028654f * 0.044715f : 0.0f);
+            // x * sigmoid(2u) == 0.5 x (1 + tanh u): act_pair, two elements per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: both
+            // groups run their epilogues in the same interval, no MFMA stream is issuing beside them); FF1 382 -> 368 us,
+            // profiles/r02/gemm_ab_pkact*.txt
+            float k1, k3;
+            act_consts(e.act, k1, k3);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -613,14 +648,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                             for (int j = 0; j < 4; j += 2) {
-                                // two elements per instruction for the polynomial, the +1 and the final product (v_pk_mul_f32 /
-                                // v_pk_fma_f32 / v_pk_add_f32: both groups run their epilogues in the same interval, no MFMA stream
-                                // is issuing beside them); FF1 382 -> 368 us, profiles/r02/gemm_ab_pkact*.txt
-                                typedef __attribute__((ext_vector_type(2))) float f32x2;
-                                const f32x2 xv = {acc[mh][nh][mi][ni][j], acc[mh][nh][mi][ni][j + 1]};
-                                const f32x2 t = xv * (xv * xv * k3 + k1);
-                                const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-                                const f32x2 o = xv * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                                const f32x2_t o = act_pair((f32x2_t){acc[mh][nh][mi][ni][j], acc[mh][nh][mi][ni][j + 1]}, k1, k3);
                                 acc[mh][nh][mi][ni][j] = o.x; acc[mh][nh][mi][ni][j + 1] = o.y;
                             }
         }
@@ -717,10 +745,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                             const int nl = nh * 32 + ni * 16 + cq * 4;               // feature inside the wave's 64
                             if constexpr (MODE == MODE_QKV_ROPE) {
                                 if (do_rope) {
-                                    const float4 t = cs4[nh][ni];
-                                    const float o0 = v[0] * t.x - v[1] * t.y, o1 = v[1] * t.x + v[0] * t.y;
-                                    const float o2 = v[2] * t.z - v[3] * t.w, o3 = v[3] * t.z + v[2] * t.w;
-                                    v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                                    const float4 t = cs4[nh][ni];          // (cos, sin) of the two pairs
+                                    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                                    rope_pair(a0, a1, t.x, t.y);
+                                    rope_pair(a2, a3, t.z, t.w);
+                                    v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
                                 } else {
                                 const int n0 = bn + wc * 64 + nl;
                                 if (n0 < 2 * e.rope_dim) {
@@ -728,9 +757,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                                     const int d = n0 & 63;
                                     const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
                                     const float4 sn = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
-                                    const float o0 = v[0] * c.x - v[1] * sn.x, o1 = v[1] * c.y + v[0] * sn.y;
-                                    const float o2 = v[2] * c.z - v[3] * sn.z, o3 = v[3] * c.w + v[2] * sn.w;
-                                    v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+                                    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                                    rope_pair(a0, a1, c.x, sn.x);
+                                    rope_pair(a2, a3, c.z, sn.z);
+                                    v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
                                 }
                                 }
                             }

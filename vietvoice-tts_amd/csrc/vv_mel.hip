@@ -19,8 +19,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const int16_t* __restrict__ au
     float* ts = tc + n_fft;              // [n_fft]
     float* mag = ts + n_fft;             // [n_fft/2 + 1]
     const int b = blockIdx.y, f = blockIdx.x;
-    const int S = audio_len[b];
-    const int frames = S / hop + 1;
+    const int S = max(audio_len[b], 1);       // an empty clip reads the row's first (padding) sample, never a[-1]
+    const int frames = audio_len[b] / hop + 1;
     const int nb = n_fft / 2 + 1;
     if (f >= frames) {                   // frames beyond this clip: defined zeros (never read as reference)
         for (int m = threadIdx.x; m < n_mel; m += 256) mel[((size_t)b * F_max + f) * n_mel + m] = 0.f;

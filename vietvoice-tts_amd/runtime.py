@@ -100,6 +100,8 @@ EXPORTS = {
     "vv_set_time_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_preprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vv_preprocess_h": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_transformer_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vv_transformer_steps_h": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -266,8 +268,10 @@ class HipSynth:
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, audio: torch.Tensor, audio_len: torch.Tensor, text_ids: torch.Tensor, text_len: torch.Tensor,
-                   seq_len: torch.Tensor, N: int, max_audio_len: Optional[int] = None, seq_len_host=None) -> Dict[str, torch.Tensor]:
-        """audio int16 [B,S], text_ids int32 [B,T], *_len int32 [B] -- all on the device."""
+                   seq_len: torch.Tensor, N: int, max_audio_len: Optional[int] = None, seq_len_host=None,
+                   audio_len_host=None) -> Dict[str, torch.Tensor]:
+        """audio int16 [B,S], text_ids int32 [B,T], *_len int32 [B] -- all on the device.  audio_len_host (optional, the same
+        values as audio_len): lets the call refuse a clip too short for the centred STFT (< n_fft/2 + 1 samples) before launching."""
         B = audio.shape[0]
         for t, d in ((audio, torch.int16), (audio_len, torch.int32), (text_ids, torch.int32), (text_len, torch.int32), (seq_len, torch.int32)):
             assert t.is_cuda and t.dtype == d and t.is_contiguous(), "preprocess inputs must be contiguous device tensors"
@@ -277,9 +281,15 @@ class HipSynth:
         ref_len = torch.empty((B,), dtype=torch.int32, device=self.device)
         mal = int(max_audio_len if max_audio_len is not None else audio.shape[1])
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.vv_preprocess(self.ctx, B, N, audio.data_ptr(), audio.shape[1], mal, audio_len.data_ptr(),
-                                               text_ids.data_ptr(), text_ids.shape[1], text_len.data_ptr(), seq_len.data_ptr(),
-                                               cat.data_ptr(), cat_drop.data_ptr(), ref_len.data_ptr(), self._stream()))
+            if audio_len_host is not None:
+                host = (C.c_int32 * B)(*[int(v) for v in audio_len_host])
+                self._check(self.lib.vv_preprocess_h(self.ctx, B, N, audio.data_ptr(), audio.shape[1], mal, audio_len.data_ptr(), host,
+                                                     text_ids.data_ptr(), text_ids.shape[1], text_len.data_ptr(), seq_len.data_ptr(),
+                                                     cat.data_ptr(), cat_drop.data_ptr(), ref_len.data_ptr(), self._stream()))
+            else:
+                self._check(self.lib.vv_preprocess(self.ctx, B, N, audio.data_ptr(), audio.shape[1], mal, audio_len.data_ptr(),
+                                                   text_ids.data_ptr(), text_ids.shape[1], text_len.data_ptr(), seq_len.data_ptr(),
+                                                   cat.data_ptr(), cat_drop.data_ptr(), ref_len.data_ptr(), self._stream()))
         return {"cat_mel_text": cat, "cat_mel_text_drop": cat_drop, "ref_signal_len": ref_len, "seq_len": seq_len,
                 "seq_len_host": None if seq_len_host is None else [int(v) for v in seq_len_host],
                 "rope_cos_q": self.rope[0][:N], "rope_sin_q": self.rope[1][:N], "rope_cos_k": self.rope[2][:N],
@@ -342,11 +352,13 @@ class HipSynth:
         return pcm, pcm_len
 
     def synthesize_batch(self, audio, audio_len, text_ids, text_len, seq_len, N: int, noise: torch.Tensor, t_gen_max: int,
-                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None, gen_frames=None, seq_len_host=None):
+                         n_steps: Optional[int] = None, max_audio_len: Optional[int] = None, gen_frames=None, seq_len_host=None,
+                         audio_len_host=None):
         """Whole hot path for a batch, state resident in HBM: preprocess -> ODE steps -> vocoder.
         gen_frames (host list, optional): per-item generated frames; lets the vocoder run in length buckets on ragged batches.
         seq_len_host (optional): the lengths on the host too -- the Euler-step call then runs without any stream synchronisation."""
-        pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len, seq_len_host=seq_len_host)
+        pre = self.preprocess(audio, audio_len, text_ids, text_len, seq_len, N, max_audio_len, seq_len_host=seq_len_host,
+                              audio_len_host=audio_len_host)
         x = noise.clone()
         self.transformer_steps(x, pre, 0, self.n_steps if n_steps is None else n_steps)
         if gen_frames is not None and len(gen_frames) == x.shape[0]:
