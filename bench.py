@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--nfe", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resident", action="store_true", help="keep inputs and PCM in HBM (no PCIe leg in the timed step)")
+    ap.add_argument("--graph-steps", action="store_true", help="replay all Euler steps + the decode of a batch from ONE captured hipGraph "
+                    "(runtime.GraphedSteps; the single-utterance latency experiment: --batch 1 --graph-steps)")
     ap.add_argument("--spec", default="full", choices=["full", "small", "tiny"])
     ap.add_argument("--workload", default="batch32", choices=["batch32", "mixed256", "longform"],
                     help="batch32 = the headline metric (BASELINE configs[2]); mixed256 = configs[3] (32 ragged units per GPU); "
@@ -267,6 +269,7 @@ def main():
         batches, audio_s_rank, nb, fill = [(d, N, GEN_FRAMES)], a.batch * GEN_FRAMES * spec.hop_length / spec.sample_rate, a.batch, 1.0
 
     pcm_host = [None] * len(batches)          # pinned landing buffers for the D2H leg, allocated by the first (warm-up) step
+    graphs = [None] * len(batches)            # --graph-steps: one captured (steps + decode) graph per batch shape
 
     def step(pcie=not a.resident):
         """host inputs -> H2D -> three stages -> D2H of the PCM; returns when the PCM is on the host."""
@@ -276,8 +279,14 @@ def main():
                 audio, ids, noise = (d["host"][k].to(device, non_blocking=True) for k in ("audio", "ids", "noise"))
             else:
                 audio, ids, noise = d["audio"], d["ids"], d["noise"]
-            o = eng.synthesize_batch(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, noise, t_gen, gen_frames=d.get("gen_frames"),
-                                     seq_len_host=d.get("seq_len_host"))
+            if a.graph_steps:
+                pre = eng.preprocess(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, seq_len_host=d["seq_len_host"])
+                if graphs[i] is None:
+                    graphs[i] = eng.capture_steps(d["seq_len"].numel(), N, d["seq_len_host"], t_gen)
+                o = graphs[i](noise, pre) + (pre,)
+            else:
+                o = eng.synthesize_batch(audio, d["audio_len"], ids, d["text_len"], d["seq_len"], N, noise, t_gen, gen_frames=d.get("gen_frames"),
+                                         seq_len_host=d.get("seq_len_host"))
             if pcie:
                 if pcm_host[i] is None:
                     pcm_host[i] = (torch.empty(o[1].shape, dtype=o[1].dtype).pin_memory(), torch.empty(o[2].shape, dtype=o[2].dtype).pin_memory())
@@ -329,7 +338,9 @@ def main():
 
     # ---- per-kernel-class timing with HIP events on the launch stream (one extra, untimed pass)
     eng.prof_enable(True)
+    was_graph, a.graph_steps = a.graph_steps, False       # events cannot be recorded inside a replayed graph: the profiled pass runs eagerly
     step()
+    a.graph_steps = was_graph
     prof = eng.prof_collect()
     eng.prof_enable(False)
     gm = prof["gemm"]
@@ -402,6 +413,8 @@ def main():
         "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
     }
     res["devices"] = devices
+    if a.graph_steps:
+        res["graph_steps"] = "all Euler steps + decode replayed from one captured hipGraph per batch shape (kernel-class timings from an eager pass)"
     if bcast_ms is not None:
         res["weight_pack_and_broadcast_ms"] = round(bcast_ms, 2)
         res["dist_backend"] = "nccl (RCCL)" if backend == "nccl" else backend + " (rehearsal: ranks may share a card)"

@@ -119,6 +119,17 @@ VV_API int vv_transformer_steps_h(vv_ctx* ctx, int B, int N, const int32_t* seq_
 VV_API int vv_decode(vv_ctx* ctx, int B, int N, const float* x, const int32_t* ref_signal_len, const int32_t* seq_len,
               int t_gen_max, int16_t* pcm, int ld_pcm, int32_t* pcm_len, float* wave_f32, void* stream);
 
+/* vv_transformer_steps_h with every intermediate carved from a CALLER-OWNED device block `ws` (256-byte aligned, >=
+ * vv_transformer_ws_bytes for the same B, N and host lengths) instead of the context arena: no allocation, no synchronisation and
+ * nothing that can move -- the form to capture into a hipGraph (all Euler steps of an utterance + vv_decode_into as ONE graph
+ * launch: the single-utterance latency path).  No reference counterpart (the reference pays a host round trip per step,
+ * core/tts_engine.py:157-172). */
+VV_API int vv_transformer_ws_bytes(vv_ctx* ctx, int B, int N, const int32_t* seq_len_host, uint64_t* bytes);
+VV_API int vv_transformer_steps_into(vv_ctx* ctx, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x,
+                              const float* cat_mel_text, const float* cat_mel_text_drop, const float* rope_cos_q,
+                              const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k, int step0,
+                              int n_steps, void* ws, uint64_t ws_bytes, void* stream);
+
 /* The same decode stage with every intermediate carved from a CALLER-OWNED device block `ws` (256-byte aligned,
  * >= vv_decode_ws_bytes bytes) instead of the context arena.  The context arena may be reallocated by any later call
  * that needs more bytes (vv_ws_generation counts those moves); a launch sequence captured into a hipGraph

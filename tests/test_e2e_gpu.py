@@ -263,6 +263,72 @@ def test_bf16_pipeline_through_the_persistent_gemm(hip_tiny):
     eng.close()
 
 
+def test_bf16_item_in_a_batch_equals_the_item_alone_across_gemm_kernels():
+    """Round 4: the reference synthesises every unit as an independent B = 1 call (/root/reference/vietvoicetts/core/tts_engine.py:47,121),
+    so an item inside a batch must equal the same item alone -- in bf16 too, although the packed batch (>= 4096 rows) takes the
+    persistent 256 x 256 GEMM and the item alone the 128 x 128 kernel.  Both kernels contract K in the same order with the same MFMA,
+    start their accumulators at the bias and share one epilogue arithmetic (vv_gemm.hip: act_pair / rope_pair), every other kernel is
+    row- or sequence-local: state and PCM are BIT-IDENTICAL ('small' preset: D = 256, 3 blocks; ragged batch of four)."""
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec = ModelSpec.small()
+    w = make_synthetic_weights(spec, seed=4242)
+    eng = HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=6)
+    la = [256 * 60, 256 * 45 + 17, 256 * 70, 256 * 52]
+    lt = [40, 33, 47, 38]
+    gf = [560, 520, 470, 540]
+    batch = make_batch(spec, la, lt, gf, seed=78)
+    assert 2 * int(batch["seq_len"].sum()) >= 4096 and 2 * int(batch["seq_len"].max()) < 4096
+    pre, x, pcm, pcm_len, _w = run_hip(eng, batch, 5, want_wave=False)
+    for b in range(4):
+        sl = int(batch["seq_len"][b])
+        one = dict(audio=batch["audio"][b:b + 1, : la[b]].contiguous(), audio_len=batch["audio_len"][b:b + 1], ids=batch["ids"][b:b + 1, : lt[b]].contiguous(),
+                   text_len=batch["text_len"][b:b + 1], seq_len=batch["seq_len"][b:b + 1], N=sl, noise=batch["noise"][b:b + 1, :sl].contiguous(), t_gen_max=gf[b])
+        _p, x1, pcm1, pcm_len1, _w1 = run_hip(eng, one, 5, want_wave=False)
+        n = int(pcm_len1[0])
+        assert n == int(pcm_len[b]) == gf[b] * spec.hop_length
+        assert torch.equal(x1[0], x[b, :sl]), (b, float((x1[0] - x[b, :sl]).abs().max()))
+        assert torch.equal(pcm1[0, :n], pcm[b, :n]), b
+    eng.close()
+
+
+def test_captured_step_loop_and_decode_equal_eager():
+    """all Euler steps (vv_transformer_steps_into) + the decode (vv_decode_into) captured into ONE hipGraph
+    (runtime.GraphedSteps: static buffers and one workspace block owned by the graph object) and replayed: state and PCM bit-identical
+    to the eager calls, at 'small' in bf16 and fp32, on a ragged batch; a second replay with other inputs of the same lengths is
+    right too (nothing of the first call is baked in), and the context arena may be reallocated in between."""
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec = ModelSpec.small()
+    w = make_synthetic_weights(spec, seed=4242)
+    for dt in ("bf16", "fp32"):
+        eng = HipSynth(spec, w, acoustic_dtype=dt, nfe_step=6)
+        la, lt, gf = [256 * 20, 256 * 12 + 100, 256 * 30], [30, 11, 47], [24, 9, 40]
+        graphs = None
+        for seed in (5, 6):
+            batch = make_batch(spec, la, lt, gf, seed=seed)
+            d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            lens = [int(v) for v in batch["seq_len"]]
+            pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"], seq_len_host=lens)
+            x_e = d["noise"].clone()
+            eng.transformer_steps(x_e, pre, 0, eng.n_steps)
+            pcm_e, len_e = eng.decode(x_e, pre, batch["t_gen_max"])
+            if graphs is None:
+                graphs = eng.capture_steps(len(la), d["N"], lens, batch["t_gen_max"])
+                # grow the context arena after the capture: the graph must not point into it
+                big = make_batch(spec, [256 * 90] * 4, [60] * 4, [300] * 4, seed=1)
+                run_hip(eng, big, 1, want_wave=False)
+            x_g, pcm_g, len_g = graphs(d["noise"], pre)
+            torch.cuda.synchronize()
+            assert torch.equal(x_g, x_e), (dt, seed)
+            assert torch.equal(len_g, len_e) and torch.equal(pcm_g, pcm_e), (dt, seed)
+        with pytest.raises(RuntimeError, match="workspace block too small"):
+            eng._check(eng.lib.vv_transformer_steps_into(eng.ctx, 3, d["N"], d["seq_len"].data_ptr(), graphs._host, x_e.data_ptr(), pre["cat_mel_text"].data_ptr(),
+                                                         pre["cat_mel_text_drop"].data_ptr(), eng.rope[0].data_ptr(), eng.rope[1].data_ptr(), eng.rope[2].data_ptr(),
+                                                         eng.rope[3].data_ptr(), 0, 1, graphs.ws.data_ptr(), 4096, torch.cuda.current_stream().cuda_stream))
+        eng.close()
+
+
 def test_full_size_model_properties():
     """BASELINE's full architecture (22 x 1024, 336 M parameters, bf16 acoustic), N = 1600-frame utterances: size-independent
     properties, no oracle run needed.  (a) splitting the Euler steps across calls is bit-exact; (b) an utterance synthesised

@@ -430,12 +430,15 @@ int vv_preprocess_h(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio,
 }
 
 // --------------------------------------------------------------------------- transformer steps
+// ws_only != nullptr: only compute the workspace bytes the call would carve (nothing is launched; the data pointers may be null).
+// ext_ws != nullptr: carve from that caller-owned block instead of the context arena (what a captured hipGraph must point into).
 static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x, const float* cat,
                                   const float* cat_drop, const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k,
-                                  const float* rope_sin_k, int step0, int n_steps, void* stream) {
+                                  const float* rope_sin_k, int step0, int n_steps, void* stream, void* ext_ws = nullptr,
+                                  uint64_t ext_bytes = 0, uint64_t* ws_only = nullptr) {
     if (!c) return -22;
     if (!c->finalized || !c->modtab) return c->fail(-1, "vv_transformer_steps: weights/time grid not ready");
-    if (B < 1 || N < 1 || !seq_len || !x || !cat || !cat_drop || !rope_cos_q || !rope_sin_q || !rope_cos_k || !rope_sin_k)
+    if (B < 1 || N < 1 || (!ws_only && (!seq_len || !x || !cat || !cat_drop || !rope_cos_q || !rope_sin_q || !rope_cos_k || !rope_sin_k)))
         return c->fail(-22, "vv_transformer_steps: bad arguments");
     if (step0 < 0 || n_steps < 0 || step0 + n_steps > c->n_steps) return c->fail(-22, "vv_transformer_steps: steps [%d,%d) outside the time grid (%d)", step0, step0 + n_steps, c->n_steps);
     const vv_model_cfg& g = c->cfg;
@@ -483,7 +486,9 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * n_tab);
     nd.add(4ull * R * 64); nd.add(4ull * R * 64);
     nd.add(4 * tail_rows * D * (tp_o > 1 ? tp_o : 0)); nd.add(4 * tail_rows * D * (tp_f > 1 ? tp_f : 0));
-    if (int r = ensure_ws(c, nd.b)) return r;
+    if (ws_only) { *ws_only = (uint64_t)align_up(nd.b, 256); return 0; }
+    if (ext_ws) { if (int r = use_ws(c, ext_ws, (size_t)ext_bytes, nd.b)) return r; }
+    else if (int r = ensure_ws(c, nd.b)) return r;
     char* xcat = carve<char>(c, es * R * KP);
     char* h = carve<char>(c, es * R * D);
     char* h2 = carve<char>(c, es * R * D);
@@ -607,6 +612,21 @@ int vv_transformer_steps_h(vv_ctx* c, int B, int N, const int32_t* seq_len, cons
                            const float* rope_sin_k, int step0, int n_steps, void* stream) {
     if (c && !seq_len_host) return c->fail(-22, "vv_transformer_steps_h: host lengths missing");
     return transformer_steps_impl(c, B, N, seq_len, seq_len_host, x, cat, cat_drop, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, step0, n_steps, stream);
+}
+
+// The same call with every intermediate carved from a CALLER-OWNED block (>= vv_transformer_ws_bytes for the same B, N and host
+// lengths, 256-byte aligned): no allocation and no synchronisation anywhere in the call, and nothing it points at can move -- the
+// form to capture into a hipGraph (all Euler steps of an utterance + vv_decode_into = one graph launch).
+int vv_transformer_ws_bytes(vv_ctx* c, int B, int N, const int32_t* seq_len_host, uint64_t* bytes) {
+    if (c && (!seq_len_host || !bytes)) return c->fail(-22, "vv_transformer_ws_bytes: bad arguments");
+    return transformer_steps_impl(c, B, N, nullptr, seq_len_host, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, bytes);
+}
+
+int vv_transformer_steps_into(vv_ctx* c, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x, const float* cat,
+                              const float* cat_drop, const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k,
+                              const float* rope_sin_k, int step0, int n_steps, void* ws, uint64_t ws_bytes, void* stream) {
+    if (c && (!seq_len_host || !ws)) return c->fail(-22, "vv_transformer_steps_into: host lengths and a workspace block are required");
+    return transformer_steps_impl(c, B, N, seq_len, seq_len_host, x, cat, cat_drop, rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, step0, n_steps, stream, ws, ws_bytes);
 }
 
 // --------------------------------------------------------------------------------------- decode

@@ -106,6 +106,9 @@ EXPORTS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vv_transformer_steps_h": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vv_transformer_ws_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "vv_transformer_steps_into": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vv_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_decode_ws_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
@@ -375,6 +378,10 @@ class HipSynth:
         Long-form synthesis replays it per chunk group: ~80 launches become one graph launch."""
         return GraphedDecode(self, B, N, t_gen_max)
 
+    def capture_steps(self, B: int, N: int, seq_len_host, t_gen_max: int) -> "GraphedSteps":
+        """Capture all Euler steps + the decode of one batch shape into ONE hipGraph (single-utterance latency path)."""
+        return GraphedSteps(self, B, N, seq_len_host, t_gen_max)
+
     # ------------------------------------------------------------------ reference-clip ingest (N3)
     def resample_poly(self, x: torch.Tensor, taps: torch.Tensor, up: int, down: int, skip: int, n_out: int) -> torch.Tensor:
         """x f32 [n_in] and taps f64 [n_taps] on the device -> f32 [n_out]."""
@@ -458,6 +465,65 @@ class GraphedDecode:
 
     def io_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.x, self.ref_len, self.seq_len, self.pcm, self.pcm_len))
+
+
+class GraphedSteps:
+    """ONE hipGraph for the whole ODE integration + decode of a fixed batch shape (B, N, the per-item lengths, t_gen_max): all
+    ``n_steps`` Euler steps (``vv_transformer_steps_into``: ~170 launches per step at the full model) and the decode stage
+    (``vv_decode_into``) are captured once and replayed as a single graph launch -- the single-utterance latency path, where the ~5,300
+    launch-sized kernels of an utterance are bound by launch cadence, not by the kernels.  The row count of every launch is part
+    of the captured shapes, so a graph serves exactly one tuple of lengths; static I/O buffers and ONE workspace block (the steps and
+    the decode run one after the other on one stream and share it) are owned here.  ``__call__`` copies the inputs in and replays.
+    No reference counterpart: the reference pays a host round trip per step (core/tts_engine.py:157-172)."""
+
+    def __init__(self, eng: HipSynth, B: int, N: int, seq_len_host, t_gen_max: int, n_steps: Optional[int] = None):
+        self.eng, self.B, self.N, self.t_gen_max = eng, int(B), int(N), int(t_gen_max)
+        self.seq_host = [int(v) for v in seq_len_host]
+        assert len(self.seq_host) == self.B
+        self.n_steps = eng.n_steps if n_steps is None else int(n_steps)
+        dev, s = eng.device, eng.spec
+        self.x = torch.zeros((B, N, s.n_mel), dtype=torch.float32, device=dev)
+        self.cat = torch.zeros((B, N, s.cond_dim), dtype=torch.float32, device=dev)
+        self.cat_drop = torch.zeros_like(self.cat)
+        self.seq_len = torch.tensor(self.seq_host, dtype=torch.int32, device=dev)
+        self.ref_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.pcm = torch.zeros((B, t_gen_max * s.hop_length), dtype=torch.int16, device=dev)
+        self.pcm_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._host = (C.c_int32 * B)(*self.seq_host)
+        nb_t, nb_d = C.c_uint64(), C.c_uint64()
+        eng._check(eng.lib.vv_transformer_ws_bytes(eng.ctx, B, N, self._host, C.byref(nb_t)))
+        eng._check(eng.lib.vv_decode_ws_bytes(eng.ctx, B, t_gen_max, C.byref(nb_d)))
+        self.ws = torch.empty((max(int(nb_t.value), int(nb_d.value)),), dtype=torch.uint8, device=dev)
+        self._launch()                                   # warm-up: sets kernel attributes before capture
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._launch()
+
+    def _launch(self):
+        e = self.eng
+        with e._lock, torch.cuda.device(e.device):
+            e._check(e.lib.vv_transformer_steps_into(e.ctx, self.B, self.N, self.seq_len.data_ptr(), self._host, self.x.data_ptr(),
+                                                     self.cat.data_ptr(), self.cat_drop.data_ptr(), e.rope[0].data_ptr(), e.rope[1].data_ptr(),
+                                                     e.rope[2].data_ptr(), e.rope[3].data_ptr(), 0, self.n_steps, self.ws.data_ptr(), self.ws.numel(),
+                                                     e._stream()))
+            e._check(e.lib.vv_decode_into(e.ctx, self.B, self.N, self.x.data_ptr(), self.ref_len.data_ptr(), self.seq_len.data_ptr(),
+                                          self.t_gen_max, self.pcm.data_ptr(), self.pcm.shape[1], self.pcm_len.data_ptr(), None,
+                                          self.ws.data_ptr(), self.ws.numel(), e._stream()))
+
+    def __call__(self, noise: torch.Tensor, pre: Dict[str, torch.Tensor]):
+        """noise [B,N,n_mel] and ``pre`` (HipSynth.preprocess of the same batch) -> (x, pcm, pcm_len): views of the static buffers,
+        valid until the next call."""
+        with self.eng._lock:
+            self.x.copy_(noise)
+            self.cat.copy_(pre["cat_mel_text"])
+            self.cat_drop.copy_(pre["cat_mel_text_drop"])
+            self.ref_len.copy_(pre["ref_signal_len"])
+            self.graph.replay()
+        return self.x, self.pcm, self.pcm_len
+
+    def pinned_bytes(self) -> int:
+        return self.ws.numel() + sum(t.numel() * t.element_size() for t in (self.x, self.cat, self.cat_drop, self.pcm))
 
 
 class DecodeGraphCache:
