@@ -148,6 +148,108 @@ def longform(a):
                                  "chunks": chunks, "spec": a.spec}}), flush=True)
 
 
+SERVE_SENTENCES = [
+    "Hôm nay trời đẹp quá, chúng ta cùng nhau đi dạo quanh hồ và ngắm hoa nở bên đường nhé.",
+    "Bản tin thời sự tối nay có những nội dung chính sau đây, mời quý vị và các bạn cùng theo dõi.",
+    "Ngày xửa ngày xưa, ở một ngôi làng nhỏ bên bờ sông, có một cậu bé rất thích nghe kể chuyện.",
+    "Cảm ơn các bạn đã lắng nghe, hẹn gặp lại các bạn trong chương trình lần sau.",
+    "Xin vui lòng giữ máy trong giây lát, chúng tôi sẽ kết nối bạn với nhân viên hỗ trợ.",
+    "Thật vậy sao, tôi chưa từng nghe điều đó bao giờ, bạn kể thêm cho tôi nghe đi.",
+]
+SERVE_VOICES = [dict(), dict(gender="male", group="news", area="southern", emotion="serious"), dict(gender="female", group="story", area="northern", emotion="happy"),
+                dict(gender="male", group="audiobook", area="central", emotion="neutral"), dict(gender="female", group="interview", area="southern", emotion="surprised")]
+
+
+def serve_requests(n: int):
+    """The seeded request list of --workload serve: 1-3 sentences (the reference's sample texts are 51-148 characters,
+    models/reference_samples.csv), five built-in voices, two speeds."""
+    g = torch.Generator().manual_seed(SEED + 5)
+    reqs = []
+    for i in range(n):
+        k = 1 + int(torch.randint(0, 3, (1,), generator=g))
+        idx = torch.randperm(len(SERVE_SENTENCES), generator=g)[:k].tolist()
+        reqs.append(dict(text=" ".join(SERVE_SENTENCES[j] for j in idx), speed=(0.9, 1.2)[int(torch.randint(0, 2, (1,), generator=g))],
+                         voice=SERVE_VOICES[int(torch.randint(0, len(SERVE_VOICES), (1,), generator=g))], serial=i))
+    return reqs
+
+
+def serve(a):
+    """SURVEY 8(f) N2 measured: what the batching front end SERVES.  16 client threads issue 96 requests (closed loop: a client sends its
+    next request when the previous one returned) against ONE TTSEngine(model_spec=full, bf16) behind BatchingFrontend, next to the same
+    requests issued one at a time through TTSEngine.synthesize -- the reference REST layer's behaviour: one shared engine, requests
+    serialised (/root/reference/vietvoicetts/api/tts_engine.py:79-87).  Wall clock includes all host plumbing (voice selection, text
+    cleaning, chunk plan, cross-fade)."""
+    import tempfile
+    import threading
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    reqs = serve_requests(a.requests)
+
+    def pct(v, q):
+        v = sorted(v)
+        return v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
+
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        cfg = ModelConfig(model_cache_dir=d, synthetic_model=True, model_spec=a.spec, acoustic_dtype=a.dtype, nfe_step=a.nfe, max_batch_chunks=a.batch)
+        eng = TTSEngine(cfg)
+        for v in SERVE_VOICES:                                   # warm-up: every voice enters the HBM voice bank, kernels are configured
+            eng.config.speed = 0.9
+            eng.synthesize(SERVE_SENTENCES[0], **v)
+        # ---- serial: one request at a time through TTSEngine.synthesize (config.speed set per call, as the REST layer does)
+        torch.cuda.synchronize()
+        lat, tot = [], 0
+        t0 = time.perf_counter()
+        for r in reqs[: a.serial_requests]:
+            ts = time.perf_counter()
+            eng.config.speed = r["speed"]
+            w, _ = eng.synthesize(r["text"], **r["voice"])
+            lat.append(time.perf_counter() - ts)
+            tot += w.size
+        el = time.perf_counter() - t0
+        out["serial"] = {"requests": len(lat), "audio_s_per_s": round(tot / 24000.0 / el, 2), "requests_per_s": round(len(lat) / el, 2),
+                         "latency_p50_ms": round(pct(lat, 0.5) * 1e3, 1), "latency_p95_ms": round(pct(lat, 0.95) * 1e3, 1)}
+        eng.config.speed = 0.9
+        # ---- the front end, pipelined (overlap) and on one thread (the round-3 loop)
+        for name, overlap in (("frontend_overlapped", True), ("frontend_single_thread", False)):
+            fe = BatchingFrontend(eng, max_wait_ms=a.max_wait_ms, max_requests=a.batch, overlap=overlap)
+            lat, sizes, lock, nxt = [], [], threading.Lock(), [0]
+
+            def client():
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(reqs):
+                        return
+                    r = reqs[i]
+                    ts = time.perf_counter()
+                    w, _ = fe.submit(r["text"], speed=r["speed"], serial=r["serial"], **r["voice"]).result(timeout=600)
+                    with lock:
+                        lat.append(time.perf_counter() - ts)
+                        sizes.append(w.size)
+            ths = [threading.Thread(target=client) for _ in range(a.clients)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            el = time.perf_counter() - t0
+            st = fe.stats()
+            fe.close()
+            out[name] = {"requests": len(lat), "audio_s_per_s": round(sum(sizes) / 24000.0 / el, 2), "requests_per_s": round(len(lat) / el, 2),
+                         "latency_p50_ms": round(pct(lat, 0.5) * 1e3, 1), "latency_p95_ms": round(pct(lat, 0.95) * 1e3, 1),
+                         "batches": st["batches"], "requests_per_batch": round(st["requests_per_batch"], 2), "chunks_per_batch": round(st["chunks_per_batch"], 2),
+                         "frames_per_batch": round(st["frames_per_batch"], 1), "gpu_busy_frac": round(st["gpu_busy_s"] / el, 3)}
+        eng.cleanup()
+    best = out["frontend_overlapped"]
+    print(json.dumps({"metric": "served audio-seconds/sec through the batching front end (SURVEY 8f N2)", "value": best["audio_s_per_s"], "unit": "audio-seconds/sec",
+                      "n_gpus": 1, "steps": a.requests, "warmup": len(SERVE_VOICES), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+                      "data": "synthetic voice pack + random-init weights; seeded request list",
+                      "config": {"workload": f"serve: {a.requests} requests (1-3 sentences, 5 voices, 2 speeds), {a.clients} closed-loop client threads, "
+                                             f"max_requests={a.batch}, max_wait_ms={a.max_wait_ms}", "spec": a.spec}, **out}), flush=True)
+
+
 def cpu_baseline(spec, weights, nfe_step):
     """Oracle (kind 'port') on the host cores, bounded sample, rank 0 only."""
     from oracle.vv_oracle import Oracle
@@ -196,12 +298,19 @@ def main():
     ap.add_argument("--graph-steps", action="store_true", help="replay all Euler steps + the decode of a batch from ONE captured hipGraph "
                     "(runtime.GraphedSteps; the single-utterance latency experiment: --batch 1 --graph-steps)")
     ap.add_argument("--spec", default="full", choices=["full", "small", "tiny"])
-    ap.add_argument("--workload", default="batch32", choices=["batch32", "mixed256", "longform"],
+    ap.add_argument("--requests", type=int, default=96, help="--workload serve: requests issued through the front end")
+    ap.add_argument("--serial-requests", type=int, default=24, help="--workload serve: requests of the same list issued one at a time")
+    ap.add_argument("--clients", type=int, default=16, help="--workload serve: closed-loop client threads")
+    ap.add_argument("--max-wait-ms", type=float, default=5.0, help="--workload serve: the front end's collect window")
+    ap.add_argument("--workload", default="batch32", choices=["batch32", "mixed256", "longform", "serve"],
                     help="batch32 = the headline metric (BASELINE configs[2]); mixed256 = configs[3] (32 ragged units per GPU); "
-                         "longform = configs[4] (4k-char text through TTSEngine, 8 chunks in flight, hipGraph vocoder)")
+                         "longform = configs[4] (4k-char text through TTSEngine, 8 chunks in flight, hipGraph vocoder); "
+                         "serve = the batching front end under 16 client threads next to serial TTSEngine.synthesize calls")
     a = ap.parse_args()
     if a.workload == "longform":
         return longform(a)
+    if a.workload == "serve":
+        return serve(a)
 
     backend = os.environ.get("VV_BENCH_DIST_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the N>1 path (ranks share cuda:0)
     if a.gpus < 1:

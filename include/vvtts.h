@@ -149,6 +149,8 @@ VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the co
  * norm and the SUM rounded to bf16 once, where a row outside the tail is rounded in the GEMM epilogue: a tail row differs from
  * the plain launch by fp32 summation order -- which later bf16 roundings amplify to bf16-level noise, so with the tail on a row's
  * result depends (inside the bf16 tolerance class) on its position in the launch.  Off, it does not; the fp32 path never splits.
+ * "rope_q_attn" (bf16): 1 (default) = the query side of the rope is applied by the attention kernel while it loads Q, the QKV GEMM
+ * ropes the k columns only; 0 = all of it in the GEMM epilogue (the fp32 model always does).
  * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
@@ -185,6 +187,8 @@ typedef struct vv_gemm_args {
     void* C_tail;              /* tail_parts > 1: fp32 [tail_parts][M - tail_row0][ldc] gated products of the K parts of rows >= tail_row0
                                   (part 0 carries the bias); those rows of C are NOT written: the consumer sums the parts and rounds
                                   the sum to the output dtype once (vv_ln_args.delta_tail) */
+    int32_t rope_skip_q;       /* VV_EPI_QKV_ROPE: 1 = leave the q columns [0, rope_dim) un-roped (plain bias + store); the attention
+                                  kernel ropes them while it loads Q (vv_attn_args.rope_cs_q).  The k columns are roped as always */
 } vv_gemm_args;
 VV_API int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 /* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the
@@ -204,6 +208,10 @@ typedef struct vv_attn_args {
                                   default s * seq_n (padded layout, rows beyond kv_len are computed and ignored) */
     int32_t total_rows;        /* rows in the qkv / out buffers (bounds the K/V buffer resource; reads past it return zero).
                                   Required (> 0) with row_start; 0 = n_seq * seq_n in the padded layout */
+    const float* rope_cs_q;    /* optional (bf16 kernel): compact [seq_n][64] (cos, sin) pair table of the QUERY side (vv_rope_compact of
+                                  the q tables, which carry the softmax scale): the q columns arrive un-roped (vv_gemm_args.rope_skip_q)
+                                  and are roped here, position = row inside the sequence, in fp32 before the one rounding to bf16 the
+                                  kernel applies to Q anyway.  NULL = q is already roped */
 } vv_attn_args;
 VV_API int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
 

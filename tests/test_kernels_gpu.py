@@ -430,6 +430,73 @@ def test_attention_headline_shape_every_row(hip_tiny):
         assert worst < TOL_BF16, (worst, lens[:4])
 
 
+@pytest.mark.parametrize("M_seq,tile", [(3, 128), (24, 256)])
+def test_query_rope_in_attention_equals_rope_in_the_gemm(hip_tiny, M_seq, tile):
+    """Round 4: the query side of the rope moved from the QKV GEMM's epilogue (rope_skip_q) into the attention kernel's Q load
+    (vv_attn_args.rope_cs_q; position = row inside the sequence; ragged key lengths; the compact q table carries the softmax scale).
+    Route A = everything in the GEMM (the round-3 path, still the fp32 model's), route B = the split.  Both against an fp32 attention
+    over fp32-roped projections of the same bf16 operands, and against each other, in the bf16 tolerance class -- with the 128 x 128
+    kernel (3 sequences) and the persistent 256 x 256 kernel (24 sequences = 6,960 rows)."""
+    rt, gu = _imports()
+    from oracle.vv_oracle import Oracle
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    seq_n, heads = 290, 4
+    D = heads * 64
+    lens = [seq_n - (41 * i) % 200 for i in range(M_seq)]
+    M = M_seq * seq_n
+    g = torch.Generator().manual_seed(290 + M_seq)
+    A = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+    ang = torch.repeat_interleave(torch.arange(seq_n, dtype=torch.float32)[:, None] * inv[None, :], 2, dim=1)
+    ropes = [t.contiguous().to(dev) for t in (ang.cos() * 0.125, ang.sin() * 0.125, ang.cos(), ang.sin())]
+    cs_q = torch.zeros(seq_n, 64, device=dev)
+    gu.check(eng, eng.lib.vv_rope_compact(eng.ctx, ropes[0].data_ptr(), ropes[1].data_ptr(), cs_q.data_ptr(), seq_n, gu.stream()))
+    kv = torch.tensor(lens, dtype=torch.int32, device=dev)
+
+    def attention(qkv, table):
+        out = torch.zeros(M, D, dtype=torch.bfloat16, device=dev)
+        a = rt.vv_attn_args()
+        a.dtype = rt.VV_BF16
+        a.qkv, a.ld_qkv, a.out, a.ld_out = qkv.data_ptr(), 3 * D, out.data_ptr(), D
+        a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len = M_seq, seq_n, heads, D, kv.data_ptr()
+        a.rope_cs_q = None if table is None else table.data_ptr()
+        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        return out
+
+    qkv_a = gu.gemm(eng, A, W, bias=b, mode=1, ropes=ropes, seq_n=seq_n, rope_dim=D, tile=tile)
+    qkv_b = gu.gemm(eng, A, W, bias=b, mode=1, ropes=ropes, seq_n=seq_n, rope_dim=D, tile=tile, rope_skip_q=1)
+    assert torch.equal(qkv_a[:, D:], qkv_b[:, D:])                        # k (roped) and v columns are untouched by the option
+    plain = (A.float() @ W.float().t() + b)
+    assert gu.rel_err(qkv_b[:, :D], plain[:, :D]) < TOL_BF16             # q columns: plain projection, no rope
+    out_a, out_b = attention(qkv_a, None), attention(qkv_b, cs_q)
+    idx = (torch.arange(M) % seq_n)
+    tabs = [t.cpu()[idx] for t in ropes]
+    y = plain.cpu()
+    q = Oracle.rope_apply(y[:, :D].reshape(M, heads, 64), tabs[0], tabs[1]).reshape(M_seq, seq_n, heads, 64)
+    k = Oracle.rope_apply(y[:, D:2 * D].reshape(M, heads, 64), tabs[2], tabs[3]).reshape(M_seq, seq_n, heads, 64)
+    v = y[:, 2 * D:].reshape(M_seq, seq_n, heads, 64)
+    worst_a = worst_b = worst_ab = 0.0
+    for s_, L in enumerate(lens):
+        sc = torch.einsum("qhd,khd->hqk", q[s_], k[s_, :L])
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), v[s_, :L]).reshape(seq_n, D)[:L]
+        ga, gb = out_a[s_ * seq_n: s_ * seq_n + L].float().cpu(), out_b[s_ * seq_n: s_ * seq_n + L].float().cpu()
+        sc_ = float(ref.abs().max())
+        worst_a, worst_b = max(worst_a, float((ga - ref).abs().max()) / sc_), max(worst_b, float((gb - ref).abs().max()) / sc_)
+        worst_ab = max(worst_ab, float((ga - gb).abs().max()) / sc_)
+    print(f"\n[q rope in attention, {M_seq} sequences] vs fp32: rope in the GEMM {worst_a:.2e}, rope in attention {worst_b:.2e}; A vs B {worst_ab:.2e}")
+    assert worst_a < TOL_BF16 and worst_b < TOL_BF16 and worst_ab < TOL_BF16
+    with pytest.raises(AssertionError, match="bf16 kernel only"):
+        a = rt.vv_attn_args()
+        f32 = torch.zeros(seq_n, 3 * D, device=dev)
+        o32 = torch.zeros(seq_n, D, device=dev)
+        a.dtype, a.qkv, a.ld_qkv, a.out, a.ld_out, a.n_seq, a.seq_n, a.heads, a.dim, a.rope_cs_q = rt.VV_F32, f32.data_ptr(), 3 * D, o32.data_ptr(), D, 1, seq_n, heads, D, cs_q.data_ptr()
+        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+
+
 def test_attention_spiked_max(hip_tiny):
     """Online-softmax rescale branch: a key late in the sequence dominates one query row."""
     rt, gu = _imports()

@@ -4,8 +4,22 @@ The reference REST layer pushes each request onto a worker thread against ONE en
 mutates ``engine.config.speed`` around the call (api/tts_engine.py:64-91).  Here every request carries its own speed,
 all chunks of all waiting requests are flattened into ragged GPU batches (different reference clips per item are
 fine: per-item lengths live on the device), and each request gets its own cross-faded PCM back through a Future.
-Noise is drawn from a per-request generator seeded with (config.random_seed, request serial), so a request's audio
-does not depend on which other requests happened to share its batch.
+Noise is drawn from a per-request generator seeded with (config.random_seed, request serial), and every kernel of the
+path is row- or sequence-local with one arithmetic whatever the launch size (round 4: the split-K tail is off, the two
+GEMM kernels share their epilogue arithmetic), so a request's audio does not depend on which other requests happened to
+share its batch -- bit for bit (tests/test_engine_gpu.py::test_batching_frontend_batch_composition_invariance*).
+
+Round 4: the loop is a three-stage pipeline instead of collect -> GPU -> cross-fade -> collect on one thread:
+
+  preparer   collects requests, runs the host side of each (``select_sample``, ``_prepare_inputs``: text cleaning, chunk plan,
+             voice-bank lookup; the per-request noise draw) and hands a prepared batch to the GPU stage.  While the GPU stage is
+             busy it KEEPS COLLECTING into the waiting batch (up to ``max_requests``), so the batch that runs next holds
+             everything that arrived during the previous one: under load the collect window is the GPU time of the batch in
+             front, not ``max_wait_ms``.
+  gpu        one ragged batch after the other through ``TTSEngine._synthesize_device`` (serialised by the engine lock).
+  finisher   per-request cross-fade (host numpy, audio_processor.py:122-192) and Future completion, off the GPU stage's path.
+
+``overlap=False`` keeps the three stages on one thread in the old order (the A/B baseline and the equality test).
 """
 from __future__ import annotations
 
@@ -18,19 +32,38 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 
+class _Batch:
+    __slots__ = ("plans", "flat", "blocks", "t0", "n_req")
+
+    def __init__(self):
+        self.plans, self.flat, self.blocks, self.t0, self.n_req = [], [], [], time.time(), 0
+
+
 class BatchingFrontend:
-    def __init__(self, engine, max_wait_ms: float = 5.0, max_requests: int = 16):
+    def __init__(self, engine, max_wait_ms: float = 5.0, max_requests: int = 16, overlap: bool = True):
         self.engine = engine
         self.max_wait = max_wait_ms / 1e3
         self.max_requests = max_requests
+        self.overlap = bool(overlap)
         self._q: "queue.Queue" = queue.Queue()
+        self._ready: "queue.Queue" = queue.Queue(maxsize=1)      # prepared batches waiting for the GPU stage
+        self._done: "queue.Queue" = queue.Queue()                # synthesised batches waiting for their cross-fades
         self._serial = 0
         self._serial_lock = threading.Lock()
         self._stop = False
         self.batches_run = 0
         self.requests_done = 0
-        self._worker = threading.Thread(target=self._loop, name="vvtts-batcher", daemon=True)
-        self._worker.start()
+        self.chunks_run = 0
+        self.frames_run = 0
+        self.gpu_busy_s = 0.0
+        if self.overlap:
+            self._threads = [threading.Thread(target=self._prep_loop, name="vvtts-batcher-prep", daemon=True),
+                             threading.Thread(target=self._gpu_loop, name="vvtts-batcher-gpu", daemon=True),
+                             threading.Thread(target=self._finish_loop, name="vvtts-batcher-finish", daemon=True)]
+        else:
+            self._threads = [threading.Thread(target=self._serial_loop, name="vvtts-batcher", daemon=True)]
+        for t in self._threads:
+            t.start()
 
     def submit(self, text: str, speed: Optional[float] = None, serial: Optional[int] = None, **voice) -> Future:
         """voice: gender / group / area / emotion / sample_iteration / reference_audio / reference_text.
@@ -49,16 +82,47 @@ class BatchingFrontend:
     def close(self):
         self._stop = True
         self._q.put(None)
-        self._worker.join(timeout=60)
+        for t in self._threads:
+            t.join(timeout=60)
 
-    # ------------------------------------------------------------------ worker
-    def _collect(self) -> List[tuple]:
+    def stats(self) -> dict:
+        b = max(self.batches_run, 1)
+        return {"batches": self.batches_run, "requests": self.requests_done, "requests_per_batch": self.requests_done / b,
+                "chunks_per_batch": self.chunks_run / b, "frames_per_batch": self.frames_run / b, "gpu_busy_s": self.gpu_busy_s}
+
+    # ------------------------------------------------------------------ stage 1: collect + host preparation
+    def _prepare_one(self, req, batch: _Batch) -> None:
+        import torch
+        eng = self.engine
+        serial, text, speed, voice, fut = req
+        try:
+            ref_audio, ref_text = eng.model_session_manager.select_sample(
+                voice.get("gender"), voice.get("group"), voice.get("area"), voice.get("emotion"), voice.get("sample_iteration"),
+                voice.get("reference_audio"), voice.get("reference_text"))
+        except Exception as e:          # propagate unwrapped, as TTSEngine.synthesize does (tts_engine.py:217)
+            fut.set_exception(e)
+            return
+        try:
+            inputs = eng._prepare_inputs(ref_audio, ref_text, text, speed=speed)
+        except Exception as e:
+            fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
+            return
+        n_mel = eng.model_session_manager.spec.n_mel
+        gen = torch.Generator().manual_seed(eng.config.random_seed * 1000003 + serial)
+        batch.plans.append((fut, len(inputs)))
+        batch.flat.extend(inputs)
+        batch.blocks.extend(torch.randn((int(i[2][0]), n_mel), generator=gen, dtype=torch.float32) for i in inputs)
+        batch.n_req += 1
+
+    def _collect(self) -> Optional[_Batch]:
+        """Block for the first request, then take what arrives within ``max_wait`` (up to ``max_requests``), preparing as it goes."""
         first = self._q.get()
         if first is None:
-            return []
-        reqs = [first]
+            return None
+        batch = _Batch()
+        self._prepare_one(first, batch)
         deadline = time.monotonic() + self.max_wait
-        while len(reqs) < self.max_requests:
+        while batch.n_req < self.max_requests and not self._stop:
             left = deadline - time.monotonic()
             if left <= 0:
                 break
@@ -69,53 +133,97 @@ class BatchingFrontend:
             if nxt is None:
                 self._stop = True
                 break
-            reqs.append(nxt)
-        return reqs
+            self._prepare_one(nxt, batch)
+        return batch
 
-    def _loop(self):
-        import torch
-        eng = self.engine
+    def _prep_loop(self):
         while not self._stop:
-            reqs = self._collect()
-            if not reqs:
-                continue
-            t0 = time.time()
-            plans, flat, blocks = [], [], []
-            n_mel = eng.model_session_manager.spec.n_mel
-            for serial, text, speed, voice, fut in reqs:
-                try:
-                    ref_audio, ref_text = eng.model_session_manager.select_sample(
-                        voice.get("gender"), voice.get("group"), voice.get("area"), voice.get("emotion"), voice.get("sample_iteration"),
-                        voice.get("reference_audio"), voice.get("reference_text"))
-                except Exception as e:          # propagate unwrapped, as TTSEngine.synthesize does (tts_engine.py:217)
-                    fut.set_exception(e)
-                    continue
-                try:
-                    inputs = eng._prepare_inputs(ref_audio, ref_text, text, speed=speed)
-                except Exception as e:
-                    fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
-                    continue
-                gen = torch.Generator().manual_seed(eng.config.random_seed * 1000003 + serial)
-                plans.append((fut, len(inputs)))
-                flat.extend(inputs)
-                blocks.extend(torch.randn((int(i[2][0]), n_mel), generator=gen, dtype=torch.float32) for i in inputs)
-            if not flat:
+            batch = self._collect()
+            if batch is None:
+                break
+            # hand over; while the GPU stage still has a batch waiting in front, keep filling this one
+            while not self._stop:
+                if batch.flat:
+                    try:
+                        self._ready.put(batch, timeout=0.002)
+                        break
+                    except queue.Full:
+                        pass
+                elif batch.n_req == 0:
+                    break                                   # every request of the batch failed in preparation
+                if batch.n_req < self.max_requests:
+                    try:
+                        nxt = self._q.get(timeout=0.002)
+                    except queue.Empty:
+                        continue
+                    if nxt is None:
+                        self._stop = True
+                        break
+                    self._prepare_one(nxt, batch)
+        self._ready.put(None)
+
+    # ------------------------------------------------------------------ stage 2: the GPU
+    def _run_batch(self, batch: _Batch):
+        eng = self.engine
+        t0 = time.perf_counter()
+        with eng._lock:
+            if eng.model_session_manager.engine is not None:
+                waves = eng._synthesize_device(batch.flat, noise_blocks=batch.blocks)
+            else:
+                waves = eng._synthesize_sessions(batch.flat)      # CPU plumbing tests: the oracle sessions draw their own noise
+        self.gpu_busy_s += time.perf_counter() - t0
+        self.batches_run += 1
+        self.chunks_run += len(batch.flat)
+        self.frames_run += sum(int(i[2][0]) for i in batch.flat)
+        return waves
+
+    def _gpu_loop(self):
+        while True:
+            batch = self._ready.get()
+            if batch is None:
+                break
+            try:
+                self._done.put((batch, self._run_batch(batch), None))
+            except Exception as e:        # noqa: BLE001
+                self._done.put((batch, None, e))
+        self._done.put(None)
+
+    # ------------------------------------------------------------------ stage 3: cross-fade + completion
+    def _finish(self, batch: _Batch, waves, err) -> None:
+        eng = self.engine
+        if err is not None:
+            for fut, _n in batch.plans:
+                if not fut.done():
+                    fut.set_exception(RuntimeError(f"Speech synthesis failed: {err}"))
+            return
+        pos = 0
+        for fut, n in batch.plans:
+            try:
+                final = eng.audio_processor.concatenate_with_crossfade_improved(waves[pos: pos + n], eng.config.cross_fade_duration,
+                                                                                eng.config.sample_rate)
+                fut.set_result((final, time.time() - batch.t0))
+            except Exception as e:        # noqa: BLE001
+                fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
+            pos += n
+            self.requests_done += 1
+
+    def _finish_loop(self):
+        while True:
+            item = self._done.get()
+            if item is None:
+                break
+            self._finish(*item)
+
+    # ------------------------------------------------------------------ overlap=False: the three stages in order on one thread
+    def _serial_loop(self):
+        while not self._stop:
+            batch = self._collect()
+            if batch is None:
+                break
+            if not batch.flat:
                 continue
             try:
-                with eng._lock:
-                    if eng.model_session_manager.engine is not None:
-                        waves = eng._synthesize_device(flat, noise_blocks=blocks)
-                    else:
-                        waves = eng._synthesize_sessions(flat)      # CPU plumbing tests: the oracle sessions draw their own noise
-                self.batches_run += 1
-                pos = 0
-                for fut, n in plans:
-                    final = eng.audio_processor.concatenate_with_crossfade_improved(waves[pos: pos + n], eng.config.cross_fade_duration,
-                                                                                    eng.config.sample_rate)
-                    pos += n
-                    self.requests_done += 1
-                    fut.set_result((final, time.time() - t0))
-            except Exception as e:
-                for fut, _n in plans:
-                    if not fut.done():
-                        fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
+                waves, err = self._run_batch(batch), None
+            except Exception as e:        # noqa: BLE001
+                waves, err = None, e
+            self._finish(batch, waves, err)

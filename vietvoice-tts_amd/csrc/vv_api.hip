@@ -53,6 +53,7 @@ struct vv_ctx {
                                         // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
+    int rope_q_attn = 1;                // bf16: 1 = the QKV GEMM ropes the k columns only and the attention kernel ropes Q while loading it
     int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
                                         // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
                                         // context: 1, fp32 context: 0 -- the numerics configuration stays on the f32 instruction)
@@ -146,7 +147,7 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
-         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0) {
+         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
@@ -154,7 +155,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
-    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts;
+    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -518,6 +519,9 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     bool uniform = true;                                   // every sequence N rows: position = packed row mod N, no table lookup
     for (int b = 0; b < B; ++b) uniform = uniform && hlen[b] == N;
     const int* qkv_pos = uniform ? nullptr : row_pos;
+    // bf16: the query side of the rope moves from the QKV GEMM's epilogue into the attention kernel's Q load (option "rope_q_attn",
+    // default on; profiles/r04/attention_notes.md); the fp32 (numerics) path keeps all of it in the GEMM
+    const int q_rope_attn = (c->rope_q_attn && c->dt == VV_DTYPE_BF16) ? 1 : 0;
 
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
@@ -561,10 +565,12 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
             a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, qkv_pos, c->rope_rows)) return r;
+            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, qkv_pos, c->rope_rows,
+                             nullptr, 0, 0, q_rope_attn)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
                 t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
+                t.rope_cs_q = q_rope_attn ? csq : nullptr;
                 Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
@@ -757,6 +763,7 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
 int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
     if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
+    if (!strcmp(name, "rope_q_attn")) { c->rope_q_attn = value != 0; return 0; }
     if (!strcmp(name, "voc_x3_rows")) {
         if (value != 0 && value != 128) return c->fail(-22, "vv_set_option: voc_x3_rows takes 0 (64-row workgroups) or 128");
         c->voc_x3_rows = value; return 0;

@@ -82,10 +82,20 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
     return r;
 }
 
+// Diagnostic builds ONLY (tools/build_variants.py vv_attention abl1=-DVV_ATTN_ABLATE=1 ...; never the shipped library; results are
+// meaningless, only the time is read -- profiles/r04/attention_notes.md):
+//   1  matrix pipe + LDS reads only: no v_exp, no sums, no row max / redo, no cvt (P = the raw score registers)
+//   2  vector work only: exponentials, sums, the speculative check, cvt; the MFMAs and their LDS reads are gone (operands opaque)
+//   3  staging only: the LDS-DMA stream, its waits and the barriers
+#ifndef VV_ATTN_ABLATE
+#define VV_ATTN_ABLATE 0
+#endif
+
 // ------------------------------------------------------------------------------------ bf16
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                           const int* __restrict__ row_start, int total_rows, int heads, int n_seq) {
+                                                           const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
+                                                           const float* __restrict__ rope_cs_q) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
     const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
     if (!blk.valid) return;
@@ -112,8 +122,26 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
         qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
+        if (rope_cs_q) {
+            // Query-side RoPE here instead of in the QKV GEMM's epilogue (round 4): this lane's 8 dims are 4 interleaved pairs, the
+            // position is the row inside the sequence, the (cos, sin) pairs carry the softmax scale.  Roped in fp32 from the bf16 the
+            // GEMM stored, then scaled by log2(e) and rounded ONCE -- Q is rounded twice on its way into the MFMA either way (before:
+            // after the rope in the GEMM, and here after the log2(e) scaling).  Once per workgroup: 32 bytes x 4 per lane from an
+            // L2-resident table, against a third of the rope epilogue's table loads and in-order waits in 682 launches of the slowest GEMM.
+            const float* tq = rope_cs_q + (size_t)qrow * 64 + ds * 16 + h * 8;
+            const float4 t0 = *(const float4*)tq, t1 = *(const float4*)(tq + 4);
+            const float cs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
+            for (int j = 0; j < 8; j += 2) {
+                const float a = (float)qf[ds][j], b = (float)qf[ds][j + 1];
+                const float na = __builtin_fmaf(a, cs[j], -(b * cs[j + 1])), nb = __builtin_fmaf(b, cs[j], a * cs[j + 1]);
+                qf[ds][j] = (bf16)(na * LOG2E);
+                qf[ds][j + 1] = (bf16)(nb * LOG2E);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
+        }
     }
 
     // staging: K tile = 8 pieces of 8 rows x 128 B, V likewise; wave w issues pieces 2w, 2w+1 of each.  buffer_load ... lds (as asm
@@ -192,6 +220,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // workgroups) the one that is ready to feed the matrix pipe goes first, the ones in their softmax blocks fill in behind it.
         // 703 -> 694 us at the bench shape, bit-identical (profiles/r02/attn_ab_prio*.txt).
         auto scores = [&]() {
+#if VV_ATTN_ABLATE == 2 || VV_ATTN_ABLATE == 3
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[kb][r] = -1.0f; asm volatile("" : "+v"(s[kb][r])); }       // opaque scores, no instruction
+            return;
+#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -235,6 +270,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // which path ran.
         float psum = 0.f;
         bool redo = kt == 0;
+#if VV_ATTN_ABLATE == 1 || VV_ATTN_ABLATE == 3
+        redo = false;
+        scores();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+#else
         if (!redo) {
             scores();
             psum = exps();
@@ -268,7 +308,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             q_ext = make_q_ext(-m_new, h);
             psum = exps();
         }
+#endif
         l_run += psum;
+#if VV_ATTN_ABLATE == 3
+        continue;
+#endif
 
         // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
         __builtin_amdgcn_s_setprio(1);
@@ -278,7 +322,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             for (int st = 0; st < 2; ++st) {
                 const f32x8 pv = {s[kb][8 * st + 0], s[kb][8 * st + 1], s[kb][8 * st + 2], s[kb][8 * st + 3],
                                   s[kb][8 * st + 4], s[kb][8 * st + 5], s[kb][8 * st + 6], s[kb][8 * st + 7]};
+#if VV_ATTN_ABLATE == 1
+                typedef __attribute__((ext_vector_type(4))) float f32x4a;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, (f32x4a){pv[0], pv[2], pv[4], pv[6]});      // no cvt: raw score bits as the operand
+#else
                 const bf16x8 pf = __builtin_convertvector(pv, bf16x8);       // 4 x v_cvt_pk_bf16_f32
+#endif
+#if VV_ATTN_ABLATE == 2
+                asm volatile("" :: "v"(pf));                                  // the cvt results are consumed, the PV MFMAs and V reads are gone
+                continue;
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
@@ -454,6 +507,7 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     }
     if (a->ld_qkv < 3 * a->dim || a->ld_out < a->dim) { *err = "attention: leading dimensions too small"; return -22; }
     if (a->row_start && !a->kv_len) { *err = "attention: packed rows need kv_len"; return -22; }
+    if (a->rope_cs_q && (a->dtype != VV_BF16 || ((uintptr_t)a->rope_cs_q % 16))) { *err = "attention: the query-side rope table is taken by the bf16 kernel only, 16-byte aligned"; return -22; }
     // the last tile of the last packed sequence reads past its rows: total_rows is what bounds the K/V buffer resource there
     // (out-of-range rows read as zero), so with packed rows it cannot be defaulted
     if (a->row_start && a->total_rows <= 0) { *err = "attention: packed rows need total_rows (rows in the qkv buffer)"; return -22; }
@@ -466,7 +520,7 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
     if (a->dtype == VV_BF16)
         attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                               a->heads, a->n_seq);
+                                               a->heads, a->n_seq, a->rope_cs_q);
     else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
                                               a->heads, a->n_seq);

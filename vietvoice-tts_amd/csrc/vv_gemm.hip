@@ -53,6 +53,7 @@ struct EpiArgs {
     unsigned seq_rcp;        // ceil(2^32 / seq_n): row -> position without a table when every sequence has seq_n rows (m * seq_n < 2^32)
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
+    int rope_lo;             // first roped column: 0, or rope_dim when the q columns are roped by the attention kernel (rope_skip_q)
 };
 
 // fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
@@ -102,7 +103,7 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
         const float4 g = *(const float4*)(e.gate + n0);
         store4<To>(C + (size_t)m * ldc + n0, g.x * v0, g.y * v1, g.z * v2, g.w * v3);
     } else if constexpr (MODE == MODE_QKV_ROPE) {
-        if (n0 < 2 * e.rope_dim) {
+        if (n0 >= e.rope_lo && n0 < 2 * e.rope_dim) {
             const bool is_k = n0 >= e.rope_dim;
             const int d = n0 & 63;
             const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);       // pair-duplicated tables: c.x == c.y
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     bool do_rope = false;
                     int pos = 0;
                     if constexpr (MODE == MODE_QKV_ROPE) {
-                        const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim;
+                        const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim && bn + wc * 64 >= e.rope_lo;
                         do_rope = rope_tile && e.cs_q != nullptr;
                         if (rope_tile) {
                             const int mc = min(m, M - 1);
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                                     v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
                                 } else {
                                 const int n0 = bn + wc * 64 + nl;
-                                if (n0 < 2 * e.rope_dim) {
+                                if (n0 >= e.rope_lo && n0 < 2 * e.rope_dim) {
                                     const bool is_k = n0 >= e.rope_dim;
                                     const int d = n0 & 63;
                                     const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);
@@ -991,7 +992,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         if ((size_t)(g->M - row0) * g->ldc * 4 >= ((size_t)1 << 31)) { *err = "gemm: split-K tail buffer of 2 GiB or more"; return -22; }
         e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
     }
-    e.rope_dim = g->rope_dim; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
+    e.rope_dim = g->rope_dim; e.rope_lo = g->rope_skip_q ? g->rope_dim : 0; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
     if (g->mode == MODE_QKV_ROPE && !g->rope_pos && (unsigned long long)g->M * (unsigned long long)e.seq_n >= ((unsigned long long)1 << 32)) {
         *err = "gemm: rope without a position table needs M * seq_n < 2^32"; return -22;
     }

@@ -51,13 +51,13 @@ class vv_gemm_args(C.Structure):
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
                 ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32),
-                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p)]
+                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p), ("rope_skip_q", C.c_int32)]
 
 
 class vv_attn_args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("qkv", C.c_void_p), ("ld_qkv", C.c_int32), ("out", C.c_void_p), ("ld_out", C.c_int32),
                 ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p),
-                ("row_start", C.c_void_p), ("total_rows", C.c_int32)]
+                ("row_start", C.c_void_p), ("total_rows", C.c_int32), ("rope_cs_q", C.c_void_p)]
 
 
 class vv_ln_args(C.Structure):
