@@ -12,6 +12,23 @@ from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
 
 rounds = int(sys.argv[1])
 libs = sys.argv[2:]
+# a library may be given as path@KEY=VAL,KEY=VAL: the environment settings are applied before each of ITS calls (diagnostic builds that
+# read their switches from the environment, e.g. libvvtts_exp.so@VV_GEMM_NGROUP=4,VV_GEMM_A_NT=1) -- one library, several settings
+envs = []
+for i, p in enumerate(libs):
+    path, _, kv = p.partition("@")
+    envs.append(dict(x.split("=", 1) for x in kv.split(",") if x))
+    libs[i] = path
+labels = [os.path.basename(p)[9:-3] + ("@" + ",".join(f"{k[8:]}={v}" for k, v in e.items()) if e else "") for p, e in zip(libs, envs)]
+ENV_KEYS = sorted({k for e in envs for k in e})
+
+
+def use_env(i):
+    for k in ENV_KEYS:
+        if k in envs[i]:
+            os.environ[k] = envs[i][k]
+        else:
+            os.environ.pop(k, None)
 spec = ModelSpec.tiny()
 w = make_synthetic_weights(spec)
 dev = "cuda:0"
@@ -30,7 +47,7 @@ cs = torch.rand(1600, 64, device=dev)
 pos = (torch.arange(M, dtype=torch.int32) % 1600).to(dev)
 cs_rows = cs[pos.long()].contiguous()            # what vv_rope_rows builds once per call
 st = torch.cuda.current_stream().cuda_stream
-tot = {p: 0.0 for p in libs}
+tot = [0.0 for _ in libs]
 tiles = [int(x) for x in os.environ.get("GEMM_AB_TILES", "").split(",") if x]      # per library: vv_gemm_args.tile (0 auto, 128, 256), e.g. one library twice as 0,128
 only = [x for x in os.environ.get("GEMM_AB_SHAPES", "").split(",") if x]      # e.g. the four shapes of one DiT block for a PMC pass
 for name, mode, N, K, act in shapes:
@@ -56,6 +73,7 @@ for name, mode, N, K, act in shapes:
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr(); a.rope_pos = pos.data_ptr()
             if name.endswith("_rows") and hasattr(a, "rope_by_row"):
                 a.rope_cs_q = a.rope_cs_k = cs_rows.data_ptr(); a.rope_by_row = 1
+        use_env(li)
         for _ in range(2):
             assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
         outs.append(out); args.append(a)
@@ -87,6 +105,7 @@ for name, mode, N, K, act in shapes:
     for r in range(rounds):
         for i, (e, a) in enumerate(zip(engs, args)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            use_env(i)
             e0.record()
             for _ in range(10):
                 e.lib.vv_gemm(e.ctx, C.byref(a), st)
@@ -96,7 +115,7 @@ for name, mode, N, K, act in shapes:
     for i, p in enumerate(libs):
         t = sorted(times[i]); med = t[len(t) // 2]
         if name != "qkv_rope":
-            tot[p] += med
-        line += f"  {os.path.basename(p)[9:-3]}{('/t%d' % tiles[i]) if tiles else ''} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
+            tot[i] += med
+        line += f"  {labels[i]}{('/t%d' % tiles[i]) if tiles else ''} {med*1e3:6.1f} us ({2.0*M*N*K/med/1e9:6.0f} TF/s)"
     print(line + f"  | max diff vs first {diffs}", flush=True)
-print("sum of qkv_rope_rows + out + ff1 + ff2 (one DiT block): " + "  ".join(f"{os.path.basename(p)[9:-3]} {tot[p]*1e3:.1f} us" for p in libs), flush=True)
+print("sum of qkv_rope_rows + out + ff1 + ff2 (one DiT block): " + "  ".join(f"{labels[i]} {tot[i]*1e3:.1f} us" for i in range(len(libs))), flush=True)

@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvvtts_hip.so")
 SOURCES = ["vv_gemm", "vv_attention", "vv_elementwise", "vv_posconv", "vv_vocoder", "vv_vocoder_x3", "vv_mel", "vv_ingest", "vv_api"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result",
+         "-Werror=extra-tokens"]      # `#endif code;` silently drops the code (round 4: an uninitialised epilogue flag)
 EXTRA_FLAGS = {}      # per-file extras (none needed at present)
 LINK_FLAGS = ["-Wl,--version-script=" + os.path.join(CSRC, "vvtts.map")]      # exports = the vv_* entry points of include/vvtts.h
 

@@ -54,6 +54,11 @@ struct EpiArgs {
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
     int rope_lo;             // first roped column: 0, or rope_dim when the q columns are roped by the attention kernel (rope_skip_q)
+#ifdef VV_GEMM_EXP           // diagnostic build only (profiles/r04/gemm_notes.md)
+    int n_group;             // persistent kernel: walk the n-tiles in groups of n_group (each XCD finishes all its panels for one group of
+                             // weight tiles before the next group: the group's weights stay in that XCD's L2); 0 = all n-tiles of a panel together
+    int a_nt;                // persistent kernel: activation LDS-DMA loads carry the non-temporal hint (streamed once per n-group)
+#endif
 };
 
 // fast epilogue activations: v_exp_f32 / v_rcp_f32 forms (about 1 ulp each), no libm calls
@@ -385,7 +390,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
     auto entry = [&](int i, int& bm_, int& bn_, int& part_, int& nk_) __attribute__((always_inline)) {
         if (ks == 1 || i < n_my_main) {
             const int E = jb + i * bpx;
-            bm_ = ((E / n_tiles) * 8 + x) * 256; bn_ = (E % n_tiles) * 256; part_ = 0; nk_ = nk_full;
+#ifdef VV_GEMM_EXP
+            if (e.n_group > 0) {                       // n-group-major: (group, panel, n-tile inside the group)
+                const int P = n_main / n_tiles, per = e.n_group * P;
+                const int gq = E / per, r = E - gq * per, p = r / e.n_group;
+                bm_ = (p * 8 + x) * 256; bn_ = (gq * e.n_group + (r - p * e.n_group)) * 256;
+            } else
+#endif
+            { bm_ = ((E / n_tiles) * 8 + x) * 256; bn_ = (E % n_tiles) * 256; }
+            part_ = 0; nk_ = nk_full;
         } else {
             const int E = jb + (i - n_my_main) * bpx, c = E % cols;
             bm_ = (mt_main + (E / cols) * 8 + x) * 256; bn_ = (c / ks) * 256; part_ = c % ks; nk_ = nk_full / ks;
@@ -442,6 +455,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                 // M need no clamp: their offset is past the resource's num_records (the origin is part of the VECTOR offset, the
                 // part the hardware range-checks), so the DMA writes zeros; those rows are computed but never stored.
                 const unsigned v = voff_a[h][u] + (unsigned)bmS * (unsigned)lda * 2u;
+#ifdef VV_GEMM_EXP
+                if (e.a_nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(slot + u * 1024), 16, (int)v, Tk * 128, 0, 2);
+                else
+#endif
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(slot + u * 1024), 16, (int)v, Tk * 128, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(slot + u * 1024), 16, (int)voff_w[h][u], bnS * ldw * 2 + Tk * 128, 0, 0);
@@ -973,7 +990,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (g->lda < g->K || g->ldw < g->K) { *err = "gemm: leading dimension smaller than K"; return -22; }
     if (g->tile != 0 && g->tile != 128 && g->tile != 256) { *err = "gemm: tile must be 0 (auto), 128 or 256"; return -22; }
     if (g->tile == 256 && g->N % 256) { *err = "gemm: the 256 tile needs N % 256 == 0"; return -22; }
-    EpiArgs e;
+    EpiArgs e{};                 // value-initialised: a field this function forgets is zero, never stack garbage
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
     e.bias = g->bias; e.gate = g->gate; e.cos_q = g->cos_q; e.sin_q = g->sin_q; e.cos_k = g->cos_k; e.sin_k = g->sin_k;
     e.act = g->act; e.n_store = g->n_store > 0 ? g->n_store : g->N; e.seq_n = g->seq_n > 0 ? g->seq_n : 1;
@@ -992,7 +1009,15 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         if ((size_t)(g->M - row0) * g->ldc * 4 >= ((size_t)1 << 31)) { *err = "gemm: split-K tail buffer of 2 GiB or more"; return -22; }
         e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
     }
-    e.rope_dim = g->rope_dim; e.rope_lo = g->rope_skip_q ? g->rope_dim : 0; e.pos_tab = g->rope_pos; e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
+    e.rope_dim = g->rope_dim; e.rope_lo = g->rope_skip_q ? g->rope_dim : 0; e.pos_tab = g->rope_pos;
+#ifdef VV_GEMM_EXP
+    e.n_group = 0; e.a_nt = 0;
+    // Diagnostic build ONLY (tools/build_variants.py vv_gemm exp=-DVV_GEMM_EXP): the walk / cache-hint experiment of profiles/r04/gemm_notes.md,
+    // switched from the environment so that ONE library can be timed in all settings inside one process
+    if (const char* v = getenv("VV_GEMM_NGROUP")) { const int ng = atoi(v); if (ng > 0 && (g->N / 256) % ng == 0 && g->N / 256 > ng && !g->tail_parts) e.n_group = ng; }
+    if (const char* v = getenv("VV_GEMM_A_NT")) e.a_nt = atoi(v) != 0;
+#endif
+    e.cs_by_row = g->rope_by_row != 0 && g->rope_cs_q && g->rope_cs_k;
     if (g->mode == MODE_QKV_ROPE && !g->rope_pos && (unsigned long long)g->M * (unsigned long long)e.seq_n >= ((unsigned long long)1 << 32)) {
         *err = "gemm: rope without a position table needs M * seq_n < 2^32"; return -22;
     }
