@@ -1,9 +1,9 @@
 // K8: flash-style attention forward for gfx950, head_dim 64, key-padding mask by length.
 //
 // Q/K/V live in the fused projection buffer [rows][3*D] (q | k | v), RoPE and the softmax scale
-// already applied by the QKV GEMM epilogue (bf16: the query side optionally here, while Q is loaded).  One workgroup = 4 waves
-// = 128 queries (fp32) or 256 queries (bf16: two 32-row query blocks per wave) of one (sequence, head); a wave owns its query
-// rows and the whole 64-wide head.  K/V tiles of 64 keys stream into a double-buffered LDS ring by LDS-DMA.
+// already applied by the QKV GEMM epilogue.  One workgroup = 4 waves = 128 queries of one
+// (sequence, head); each wave owns 32 queries and the whole 64-wide head.  K/V tiles of 64 keys
+// stream into a double-buffered LDS ring by LDS-DMA (global_load_lds_dwordx4).
 //
 // The score product is computed swapped, S^T = K Q^T (MFMA A = K rows, B = Q rows), so the key
 // index lands on the accumulator registers and the query on the lane: the online-softmax row
@@ -90,57 +90,57 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 #ifndef VV_ATTN_ABLATE
 #define VV_ATTN_ABLATE 0
 #endif
-#ifndef VV_ATTN_QB
-#define VV_ATTN_QB 2          // query blocks of 32 rows per wave in the main body (1 = the round-3 kernel: 128 queries per workgroup)
-#endif
 
 // ------------------------------------------------------------------------------------ bf16
-// QB query blocks of 32 rows per wave: a workgroup of 4 waves covers 128 * QB queries of one (sequence, head).  Round 4 measured the
-// round-3 kernel (QB = 1) with its vector work removed at 92 % of its full time and its K/V staging ALONE at 52 %: 400 KB of K/V
-// per 128 queries is 5.3 GB per launch through the CUs' ~26-30 B/clk L2 -> LDS path (profiles/r04/attention_notes.md).  With
-// QB = 2 a K/V tile staged into LDS serves 64 query rows of a wave instead of 32: half the staging bytes per query.  Costs: 48 more
-// registers (two waves per SIMD instead of four; the wave carries two independent softmax streams instead) and a coarser query
-// grid -- the last block of a sequence falls back to QB = 1 when it has 128 rows or fewer left.  A row's arithmetic is the same in both bodies (same MFMA
-// sequence per 32-row block, same speculative-tile decision per 32-row block): outputs are bit-identical to the QB = 1 kernel.
-template <int QB>
-__device__ __forceinline__ void attn_bf16_body(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo, int D, int kv_len,
-                                               size_t row0, int q_lim, int total_rows, int head, int q_first,
-                                               const float* __restrict__ rope_cs_q, char* smem) {
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
+                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
+                                                           const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
+                                                           const float* __restrict__ rope_cs_q) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
+    const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
+    if (!blk.valid) return;
+    const int head = blk.head, seq = blk.seq, qblock = blk.qb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31, h = lane >> 5;
+    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
+    kv_len = max(1, min(kv_len, seq_n));
+    // packed rows (row_start given): sequence `seq` owns rows [row_start[seq], +kv_len) only -- the rows after them are the
+    // next sequence's, so queries stop at kv_len and every row index is clamped inside the sequence.
+    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
+    const int q_lim = row_start ? kv_len : seq_n;
+    if (qblock * 128 >= q_lim) return;
+
     const bf16* Qp = qkv + row0 * ld + head * 64;
     const bf16* Kp = Qp + D;
     // bytes from Kp to the end of the qkv buffer (host-checked < 2 GiB): the bound of the K/V buffer resource
     const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
 
-    const int q0 = q_first + wave * 32 * QB;
-    bf16x8 qf[QB][4];
+    const int q0 = qblock * 128 + wave * 32;
+    const int qrow = min(q0 + r32, q_lim - 1);
+    bf16x8 qf[4];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = min(q0 + qb * 32 + r32, q_lim - 1);
+    for (int ds = 0; ds < 4; ++ds) {
+        qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
+        if (rope_cs_q) {
+            // Query-side RoPE here instead of in the QKV GEMM's epilogue (round 4): this lane's 8 dims are 4 interleaved pairs, the
+            // position is the row inside the sequence, the (cos, sin) pairs carry the softmax scale.  Roped in fp32 from the bf16 the
+            // GEMM stored, then scaled by log2(e) and rounded ONCE -- Q is rounded twice on its way into the MFMA either way (before:
+            // after the rope in the GEMM, and here after the log2(e) scaling).  Once per workgroup: 32 bytes x 4 per lane from an
+            // L2-resident table, against a third of the rope epilogue's table loads and in-order waits in 682 launches of the slowest GEMM.
+            const float* tq = rope_cs_q + (size_t)qrow * 64 + ds * 16 + h * 8;
+            const float4 t0 = *(const float4*)tq, t1 = *(const float4*)(tq + 4);
+            const float cs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            qf[qb][ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
-            if (rope_cs_q) {
-                // Query-side RoPE here instead of in the QKV GEMM's epilogue (round 4): this lane's 8 dims are 4 interleaved pairs, the
-                // position is the row inside the sequence, the (cos, sin) pairs carry the softmax scale.  Roped in fp32 from the bf16 the
-                // GEMM stored, then scaled by log2(e) and rounded ONCE -- Q is rounded twice on its way into the MFMA either way (before:
-                // after the rope in the GEMM, and here after the log2(e) scaling).
-                const float* tq = rope_cs_q + (size_t)qrow * 64 + ds * 16 + h * 8;
-                const float4 t0 = *(const float4*)tq, t1 = *(const float4*)(tq + 4);
-                const float cs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const float a = (float)qf[qb][ds][j], b = (float)qf[qb][ds][j + 1];
-                    const float na = __builtin_fmaf(a, cs[j], -(b * cs[j + 1])), nb = __builtin_fmaf(b, cs[j], a * cs[j + 1]);
-                    qf[qb][ds][j] = (bf16)(na * LOG2E);
-                    qf[qb][ds][j + 1] = (bf16)(nb * LOG2E);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) qf[qb][ds][j] = (bf16)((float)qf[qb][ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
+            for (int j = 0; j < 8; j += 2) {
+                const float a = (float)qf[ds][j], b = (float)qf[ds][j + 1];
+                const float na = __builtin_fmaf(a, cs[j], -(b * cs[j + 1])), nb = __builtin_fmaf(b, cs[j], a * cs[j + 1]);
+                qf[ds][j] = (bf16)(na * LOG2E);
+                qf[ds][j + 1] = (bf16)(nb * LOG2E);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
         }
     }
 
@@ -177,21 +177,17 @@ __device__ __forceinline__ void attn_bf16_body(const bf16* __restrict__ qkv, int
         }
     };
 
-    f32x16 o[QB][2];
+    f32x16 o[2];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
-    float m_eff[QB], l_run[QB];                  // m_eff: row reference in the log2 domain, bf16-representable
-    bf16x8 q_ext[QB];                            // Q side of the 65th contraction element: -m_eff
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { m_eff[qb] = 0.f; l_run[qb] = 0.f; q_ext[qb] = make_q_ext(0.f, h); }
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_eff = 0.f, l_run = 0.f;              // m_eff: row reference in the log2 domain, bf16-representable
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     const bf16x8 k_one = make_q_ext(1.0f, h);    // K side of the 65th contraction element: 1.0 at k = 0 of lane half 0
+    bf16x8 q_ext = make_q_ext(0.f, h);           // Q side: -m_eff
 
     // transposed-read lane constants: 16-lane group g reads a 4-key x 16-d block.  Per d-tile the byte offset of this
     // lane's 8-byte piece inside a 16-key slab is a constant; (key block, k-step, +8 rows) are immediates.
@@ -214,218 +210,154 @@ __device__ __forceinline__ void attn_bf16_body(const bf16* __restrict__ qkv, int
         const char* sK = smem + (kt & 1) * 16384;
         const char* sV = sK + 8192;
 
-        // Order inside a tile (QB = 2): S(0) S(1) | E(0) | stage | PV(0) | E(1) | PV(1).  The score MFMAs of BOTH query blocks go out
-        // first (every K fragment read from LDS serves both), so block 0's exponentials run while block 1's scores are still in the
-        // matrix pipe, and block 1's exponentials run under block 0's PV: the wave overlaps its own vector and matrix work, which two
-        // waves per SIMD alone do not (measured: the blocks strictly one after the other, S E PV S E PV, ran at the SUM of the
-        // matrix-only and vector-only builds, 918 against 765 us for QB = 1; profiles/r04/attention_notes.md).
+        // ---- S'^T = K Q^T - m : scores arrive in the log2 domain (Q fragments carry log2e) and ALREADY SHIFTED by the
+        // row reference m_eff: the shift rides as a 65th contraction element (K side 1.0, Q side -m_eff, one extra MFMA
+        // per key block) instead of 32 VALU fmas per tile -- the loop is VALU-bound (profiles/r01/attention_notes.md).
+        // s[kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32
+        f32x16 s[2];
         const int kbase = kt * 64;
-        // s[qb][kb][reg] -> key kb*32 + (reg&3) + 8(reg>>2) + 4h, query r32 of block qb
-        f32x16 s[QB][2];
-        auto mask_tail = [&](int qb) {
+        // The two MFMA blocks of a tile issue at raised wave priority (s_setprio 1): among the four waves of a SIMD (four different
+        // workgroups) the one that is ready to feed the matrix pipe goes first, the ones in their softmax blocks fill in behind it.
+        // 703 -> 694 us at the bench shape, bit-identical (profiles/r02/attn_ab_prio*.txt).
+        auto scores = [&]() {
+#if VV_ATTN_ABLATE == 2 || VV_ATTN_ABLATE == 3
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[kb][r] = -1.0f; asm volatile("" : "+v"(s[kb][r])); }       // opaque scores, no instruction
+            return;
+#endif
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
             if (kbase + 64 > kv_len) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (key >= kv_len) s[qb][kb][r] = NEG_BIG;
+                        if (key >= kv_len) s[kb][r] = NEG_BIG;
                     }
             }
-        };
-        // ---- S'^T = K Q^T - m : scores arrive in the log2 domain (Q fragments carry log2e) and ALREADY SHIFTED by the
-        // row reference m_eff: the shift rides as a 65th contraction element (K side 1.0, Q side -m_eff, one extra MFMA
-        // per key block) instead of 32 VALU fmas per tile -- the loop is VALU-bound (profiles/r01/attention_notes.md).
-        // The MFMA blocks of a tile issue at raised wave priority (s_setprio 1): among the waves of a SIMD the one that is ready to
-        // feed the matrix pipe goes first, the ones in their softmax blocks fill in behind it (profiles/r02/attn_ab_prio*.txt).
-        auto scores_all = [&]() {
-#if VV_ATTN_ABLATE == 2 || VV_ATTN_ABLATE == 3
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { s[qb][kb][r] = -1.0f; asm volatile("" : "+v"(s[qb][kb][r])); }       // opaque scores, no instruction
-            return;
-#endif
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext[qb], zero16, 0, 0, 0);
-#pragma unroll
-                    for (int ds = 0; ds < 4; ++ds) {
-                        const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
-                        s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], s[qb][kb], 0, 0, 0);
-                    }
-                }
-            __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) mask_tail(qb);
-        };
-        auto scores_one = [&](int qb) {           // the careful path recomputes one query block's scores against its current reference
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext[qb], zero16, 0, 0, 0);
-#pragma unroll
-                for (int ds = 0; ds < 4; ++ds) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], s[qb][kb], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            mask_tail(qb);
         };
         // p = 2^s' in place, returns this half-wave's partial row sum.  Single f32 instructions on purpose -- packed f32 VALU
         // (v_pk_fma/add_f32) issues slowly beside MFMAs on gfx950 (measured 1011 -> 989 us when unpacked).
-        auto exps = [&](int qb) -> float {
+        auto exps = [&]() -> float {
             float ps[4] = {0.f, 0.f, 0.f, 0.f};          // four independent sum chains
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = fast_exp2(s[qb][kb][r]);
+                    const float pv = fast_exp2(s[kb][r]);
                     ps[r & 3] += pv;
-                    s[qb][kb][r] = pv;
+                    s[kb][r] = pv;
                 }
             return (ps[0] + ps[1]) + (ps[2] + ps[3]);
         };
-#if VV_ATTN_ABLATE != 1 && VV_ATTN_ABLATE != 3
-        if (kt != 0) scores_all();
-#else
-        scores_all();
-#endif
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            // Online softmax with a SPECULATIVE tile: the exponentials are taken against the stale reference m_eff without looking
-            // for the row max first (21 VALU instructions per tile); the partial row sums then tell whether that was safe -- an
-            // element above 2^8 (or an overflow to inf) puts its half-row sum above 256.  Only then (and on the first tile) the
-            // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
-            // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
-            // which path ran.  The decision is taken per 32-row query block.
-            float psum = 0.f;
-            bool redo = kt == 0;
-            // the next tile's staging goes out once per tile: between the first block's exponentials and its PV (first tile: up front)
+        // Online softmax with a SPECULATIVE tile: the exponentials are taken against the stale reference m_eff without looking
+        // for the row max first (21 VALU instructions per tile); the partial row sums then tell whether that was safe -- an
+        // element above 2^8 (or an overflow to inf) puts its half-row sum above 256.  Only then (and on the first tile) the
+        // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
+        // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
+        // which path ran.
+        float psum = 0.f;
+        bool redo = kt == 0;
 #if VV_ATTN_ABLATE == 1 || VV_ATTN_ABLATE == 3
-            redo = false;
-            if (qb == 0 && kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+        redo = false;
+        scores();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
 #else
-            if (!redo) {
-                psum = exps(qb);
-                if (qb == 0 && kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-                redo = __any(!(psum <= RESCALE_SUM));
-            }
-            else if (qb == 0 && kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
-            if (redo) {
-                scores_one(qb);
-                float mx = s[qb][0][0];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
-                mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
-                const float m_new = bf16_round(kt == 0 ? mx : m_eff[qb] + fmaxf(mx, 0.f));
-                const float d = m_new - m_eff[qb];                 // exact: both are bf16 values
-                if (kt != 0) {                                     // O and l are zero on the first tile
-                    const float alpha = fast_exp2(-d);
-                    l_run[qb] *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
-                }
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[qb][kb][r] -= d;    // this tile was shifted by the old reference
-                m_eff[qb] = m_new;
-                q_ext[qb] = make_q_ext(-m_new, h);
-                psum = exps(qb);
-            }
-#endif
-            l_run[qb] += psum;
-#if VV_ATTN_ABLATE == 3
-            continue;
-#endif
-
-            // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
-            __builtin_amdgcn_s_setprio(1);
+        if (!redo) {
+            scores();
+            psum = exps();
+            if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+            redo = __any(!(psum <= RESCALE_SUM));
+        }
+        else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
+        if (redo) {
+            scores();
+            float mx = s[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const f32x8 pv = {s[qb][kb][8 * st + 0], s[qb][kb][8 * st + 1], s[qb][kb][8 * st + 2], s[qb][kb][8 * st + 3],
-                                      s[qb][kb][8 * st + 4], s[qb][kb][8 * st + 5], s[qb][kb][8 * st + 6], s[qb][kb][8 * st + 7]};
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
+            const float m_new = bf16_round(kt == 0 ? mx : m_eff + fmaxf(mx, 0.f));
+            const float d = m_new - m_eff;                     // exact: both are bf16 values
+            if (kt != 0) {                                     // O and l are zero on the first tile
+                const float alpha = fast_exp2(-d);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= d;    // this tile was shifted by the old reference
+            m_eff = m_new;
+            q_ext = make_q_ext(-m_new, h);
+            psum = exps();
+        }
+#endif
+        l_run += psum;
+#if VV_ATTN_ABLATE == 3
+        continue;
+#endif
+
+        // ---- O^T += V^T P^T : the accumulator registers 8st..8st+7 are the B fragment of k-step st
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const f32x8 pv = {s[kb][8 * st + 0], s[kb][8 * st + 1], s[kb][8 * st + 2], s[kb][8 * st + 3],
+                                  s[kb][8 * st + 4], s[kb][8 * st + 5], s[kb][8 * st + 6], s[kb][8 * st + 7]};
 #if VV_ATTN_ABLATE == 1
-                    typedef __attribute__((ext_vector_type(4))) float f32x4a;
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, (f32x4a){pv[0], pv[2], pv[4], pv[6]});      // no cvt: raw score bits as the operand
+                typedef __attribute__((ext_vector_type(4))) float f32x4a;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, (f32x4a){pv[0], pv[2], pv[4], pv[6]});      // no cvt: raw score bits as the operand
 #else
-                    const bf16x8 pf = __builtin_convertvector(pv, bf16x8);       // 4 x v_cvt_pk_bf16_f32
+                const bf16x8 pf = __builtin_convertvector(pv, bf16x8);       // 4 x v_cvt_pk_bf16_f32
 #endif
 #if VV_ATTN_ABLATE == 2
-                    asm volatile("" :: "v"(pf));                                  // the cvt results are consumed, the PV MFMAs and V reads are gone
-                    continue;
+                asm volatile("" :: "v"(pf));                                  // the cvt results are consumed, the PV MFMAs and V reads are gone
+                continue;
 #endif
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
-                        const char* a1 = a0 + 8 * 128;
-                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
-                        const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[qb][dt], 0, 0, 0);
-                    }
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* a0 = sV + tr_off[dt] + (kb * 32 + 16 * st) * 128;
+                    const char* a1 = a0 + 8 * 128;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
+                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
-        }
+            }
+        __builtin_amdgcn_s_setprio(0);
     }
+    const float l_tot = half_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + r32;
+    if (q < q_lim) {
+        bf16* op = out + (row0 + q) * ldo + head * 64;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float l_tot = half_sum(l_run[qb]);
-        const float inv = 1.0f / l_tot;
-        const int q = q0 + qb * 32 + r32;
-        if (q < q_lim) {
-            bf16* op = out + (row0 + q) * ldo + head * 64;
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = dt * 32 + 8 * g + 4 * h;
-                    store4<bf16>(op + d0, o[qb][dt][4 * g] * inv, o[qb][dt][4 * g + 1] * inv, o[qb][dt][4 * g + 2] * inv,
-                                 o[qb][dt][4 * g + 3] * inv);
-                }
-        }
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                store4<bf16>(op + d0, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                             o[dt][4 * g + 3] * inv);
+            }
     }
-}
-
-// Workgroup -> (sequence, head, query range): block j of a pair starts at query j * 128 * QBW; a block with more than 128 rows left
-// runs the QBW-block body, the last one (128 rows or fewer left) the one-block body.
-template <int QBW>
-__global__ __launch_bounds__(256, QBW == 1 ? 4 : 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
-                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                           const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
-                                                           const float* __restrict__ rope_cs_q) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
-    const AttnBlock blk = attn_block((seq_n + 128 * QBW - 1) / (128 * QBW), heads, n_seq);
-    if (!blk.valid) return;
-    const int head = blk.head, seq = blk.seq;
-    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
-    kv_len = max(1, min(kv_len, seq_n));
-    // packed rows (row_start given): sequence `seq` owns rows [row_start[seq], +kv_len) only -- the rows after them are the
-    // next sequence's, so queries stop at kv_len and every row index is clamped inside the sequence.
-    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
-    const int q_lim = row_start ? kv_len : seq_n;
-    const int q_first = blk.qb * 128 * QBW;
-    if (q_first >= q_lim) return;
-    if constexpr (QBW > 1) {
-        if (q_lim - q_first > 128) {
-            attn_bf16_body<QBW>(qkv, ld, out, ldo, D, kv_len, row0, q_lim, total_rows, head, q_first, rope_cs_q, smem);
-            return;
-        }
-    }
-    attn_bf16_body<1>(qkv, ld, out, ldo, D, kv_len, row0, q_lim, total_rows, head, q_first, rope_cs_q, smem);
 }
 
 // ------------------------------------------------------------------------------------ fp32
@@ -582,13 +514,12 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const int total_rows = a->total_rows > 0 ? a->total_rows : a->n_seq * a->seq_n;
     if (a->dtype == VV_BF16 && (size_t)total_rows * a->ld_qkv * 2 >= ((size_t)1 << 31)) { *err = "attention: qkv buffer must stay below 2 GiB"; return -22; }
     if (a->row_start == nullptr && total_rows < a->n_seq * a->seq_n) { *err = "attention: total_rows smaller than n_seq * seq_n"; return -22; }
-    const int qrows = a->dtype == VV_BF16 ? 128 * VV_ATTN_QB : 128;            // query rows per workgroup
-    const int nqb = (a->seq_n + qrows - 1) / qrows;
+    const int nqb = (a->seq_n + 127) / 128;
     const long long pairs8 = ((long long)a->heads * a->n_seq + 7) / 8;          // (sequence, head) pairs per XCD group
     if (pairs8 * nqb * 8 > 0x7fffffffLL) { *err = "attention: grid too large"; return -22; }
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
     if (a->dtype == VV_BF16)
-        attn_bf16_kernel<VV_ATTN_QB><<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
                                                a->heads, a->n_seq, a->rope_cs_q);
     else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
