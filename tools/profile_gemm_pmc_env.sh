@@ -2,8 +2,9 @@
 # FETCH_SIZE / WRITE_SIZE / TCC hit rate of the persistent GEMM at the block's four shapes for ONE library under the caller's environment
 # (e.g. VV_GEMM_NGROUP=4 with the diagnostic build):  bash tools/profile_gemm_pmc_env.sh <tag> <lib.so>   -> gpurun_out/r04/gemm_pmc_<tag>.json
 set -u
-TAG=$1; LIB=$2
+TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+LIB=$(cd $ROOT && realpath $2)
 OUT=$ROOT/gpurun_out/r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

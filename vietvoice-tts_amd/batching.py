@@ -115,25 +115,27 @@ class BatchingFrontend:
         batch.n_req += 1
 
     def _collect(self) -> Optional[_Batch]:
-        """Block for the first request, then take what arrives within ``max_wait`` (up to ``max_requests``), preparing as it goes."""
+        """Block for the first request, then take what arrives within ``max_wait`` -- and whatever is ALREADY queued when the window
+        closes (the window bounds the wait for arrivals, not the time spent on requests that are there) -- up to ``max_requests``;
+        the host preparation of the collected requests follows."""
         first = self._q.get()
         if first is None:
             return None
-        batch = _Batch()
-        self._prepare_one(first, batch)
+        reqs = [first]
         deadline = time.monotonic() + self.max_wait
-        while batch.n_req < self.max_requests and not self._stop:
+        while len(reqs) < self.max_requests and not self._stop:
             left = deadline - time.monotonic()
-            if left <= 0:
-                break
             try:
-                nxt = self._q.get(timeout=left)
+                nxt = self._q.get(timeout=left) if left > 0 else self._q.get_nowait()
             except queue.Empty:
                 break
             if nxt is None:
                 self._stop = True
                 break
-            self._prepare_one(nxt, batch)
+            reqs.append(nxt)
+        batch = _Batch()
+        for r in reqs:
+            self._prepare_one(r, batch)
         return batch
 
     def _prep_loop(self):
