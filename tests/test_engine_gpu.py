@@ -307,7 +307,9 @@ def test_bench_json_contract():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["cores"] >= 1
-    assert d["median_ms_per_step"] > 0 and "H2D" in d["timed_region"] and "D2H" in d["timed_region"] and "hbm_target_note" in d
+    assert d["median_ms_per_step"] > 0 and "resident in HBM" in d["timed_region"] and "hbm_target_note" in d
+    pi = d["pcie_inclusive"]                       # the same step with its PCIe legs, beside `value`, never as `value`
+    assert pi["value"] > 0 and pi["steps"] >= 1 and "H2D" in pi["what"] and "D2H" in pi["what"]
 
 
 def test_bench_two_rank_branch_over_gloo():

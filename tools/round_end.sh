@@ -2,7 +2,7 @@
 # Round-end evidence on the GPU box (through gpurun from the repo root):  bash tools/round_end.sh r03
 # the whole -m gpu suite, the headline bench, the rocprofv3 kernel-trace summary of the same command, the other BASELINE configurations.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -14,6 +14,7 @@ python bench.py --workload mixed256 --steps 4 --warmup 1 --no-cpu-baseline > $OU
 python bench.py --workload longform --steps 3 --warmup 1 > $OUT/bench_longform.json 2>/dev/null; echo "longform rc=$?"
 python bench.py --batch 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_b1_bf16.json 2>/dev/null; echo "b1 bf16 rc=$?"
 python bench.py --batch 1 --dtype fp32 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_b1_fp32.json 2>/dev/null; echo "b1 fp32 rc=$?"
+python bench.py --workload serve > $OUT/bench_serve_c16.json 2>/dev/null; echo "serve rc=$?"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/prof_kt.err
 echo "kernel-trace rc=$?"
