@@ -90,17 +90,14 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 #ifndef VV_ATTN_ABLATE
 #define VV_ATTN_ABLATE 0
 #endif
-#ifndef VV_ATTN_W8
-#define VV_ATTN_W8 0          // 1: whole 256-row query blocks go to the 8-wave skewed kernel (experiment, below)
-#endif
 
 // ------------------------------------------------------------------------------------ bf16
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
                                                            const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
-                                                           const float* __restrict__ rope_cs_q, int tail_only) {
+                                                           const float* __restrict__ rope_cs_q) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
-    const AttnBlock blk = attn_block(tail_only ? 2 : (seq_n + 127) / 128, heads, n_seq);
+    const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
     if (!blk.valid) return;
     const int head = blk.head, seq = blk.seq, qblock = blk.qb;
     const int lane = threadIdx.x & 63;
@@ -112,19 +109,14 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     // next sequence's, so queries stop at kv_len and every row index is clamped inside the sequence.
     const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
     const int q_lim = row_start ? kv_len : seq_n;
-#if VV_ATTN_W8
-    const int q_base = tail_only ? (q_lim >> 8) << 8 : 0;      // tail mode: the whole 256-row blocks belong to the 8-wave kernel
-#else
-    const int q_base = 0;
-#endif
-    if (q_base + qblock * 128 >= q_lim) return;
+    if (qblock * 128 >= q_lim) return;
 
     const bf16* Qp = qkv + row0 * ld + head * 64;
     const bf16* Kp = Qp + D;
     // bytes from Kp to the end of the qkv buffer (host-checked < 2 GiB): the bound of the K/V buffer resource
     const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
 
-    const int q0 = q_base + qblock * 128 + wave * 32;
+    const int q0 = qblock * 128 + wave * 32;
     const int qrow = min(q0 + r32, q_lim - 1);
     bf16x8 qf[4];
 #pragma unroll
@@ -368,256 +360,6 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     }
 }
 
-#if VV_ATTN_W8
-// EXPERIMENT (round 4, profiles/r04/attention_notes.md section 4): 256 queries per workgroup = 8 waves x 32 rows, so that a staged K/V tile
-// serves twice the queries (the kernel is bound by K/V bytes per CU), with FOUR waves per SIMD kept (128 registers).  Round 3's plain
-// 8-wave workgroup lost 16 %: its per-tile barrier puts the two waves that share a SIMD into the same phase.  Here the second half of
-// the workgroup (waves 4-7: each shares its SIMD with wave w - 4) runs A THIRD OF A TILE BEHIND: in barrier interval kt the early waves do
-// S(kt) E(kt) PV(kt), the late waves PV(kt-1) S(kt) E(kt), carrying the converted P of a tile (16 registers) across the barrier -- for two
-// of the three blocks of an interval one wave of a SIMD is in a matrix block while its partner is in its exponentials.  The late waves
-// read V of tile kt-1 during interval kt and tiles are staged TWO ahead behind a counted wait, so the ring has four slots.  Every wave
-// passes n_tiles + 1 barriers.
-// A row's arithmetic is that of the 4-wave kernel (same MFMA sequence, same speculative decision per 32-row block): bit-identical output.
-__global__ __launch_bounds__(512, 4) void attn_bf16_w8_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
-                                                              int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
-                                                              const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
-                                                              const float* __restrict__ rope_cs_q) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 16384];   // four slots: K 8 KiB | V 8 KiB each; tiles are staged TWO ahead
-    const AttnBlock blk = attn_block(seq_n >> 8, heads, n_seq);
-    if (!blk.valid) return;
-    const int head = blk.head, seq = blk.seq;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool late = wave >= 4;
-    const int r32 = lane & 31, h = lane >> 5;
-    int kv_len = kv_len_arr ? kv_len_arr[seq] : seq_n;
-    kv_len = max(1, min(kv_len, seq_n));
-    const size_t row0 = row_start ? (size_t)row_start[seq] : (size_t)seq * seq_n;
-    const int q_lim = row_start ? kv_len : seq_n;
-    const int q_first = blk.qb * 256;
-    if (q_first + 256 > q_lim) return;                 // only whole 256-row blocks here; the rest is the 4-wave kernel's (tail mode)
-
-    const bf16* Qp = qkv + row0 * ld + head * 64;
-    const bf16* Kp = Qp + D;
-    const unsigned kv_bytes = (unsigned)(((size_t)total_rows - row0) * (size_t)ld * 2 - (size_t)(head * 64 + D) * 2);
-    const int q0 = q_first + wave * 32;
-    const int qrow = q0 + r32;                         // < q_lim: the block is whole
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-        qf[ds] = *(const bf16x8*)(Qp + (size_t)qrow * ld + ds * 16 + h * 8);
-        if (rope_cs_q) {
-            const float* tq = rope_cs_q + (size_t)qrow * 64 + ds * 16 + h * 8;
-            const float4 t0 = *(const float4*)tq, t1 = *(const float4*)(tq + 4);
-            const float cs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const float a = (float)qf[ds][j], b = (float)qf[ds][j + 1];
-                const float na = __builtin_fmaf(a, cs[j], -(b * cs[j + 1])), nb = __builtin_fmaf(b, cs[j], a * cs[j + 1]);
-                qf[ds][j] = (bf16)(na * LOG2E);
-                qf[ds][j + 1] = (bf16)(nb * LOG2E);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);
-        }
-    }
-    // staging: 8 K pieces + 8 V pieces of 8 rows x 128 B per tile; wave w issues piece w of each (half the LDS-DMA issue per wave)
-    const i32x4_t rs4 = make_rsrc4(Kp, kv_bytes);
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    unsigned voff_k, voff_v;
-    {
-        const int row = wave * 8 + (lane >> 3);
-        const int p = lane & 7;
-        const int ck = p ^ ((row >> 1) & 7);
-        const int cv = p ^ (((row >> 1) & 1) << 2);
-        voff_k = (unsigned)row * (unsigned)ld * 2u + ck * 16;
-        voff_v = (unsigned)row * (unsigned)ld * 2u + (unsigned)D * 2u + cv * 16;
-    }
-    const int tile_bytes = 64 * ld * 2;
-    // stage(kt + 2) is issued after barrier kt and writes slot (kt + 2) & 3 = (kt - 2) & 3, whose last readers (the late waves' PV of tile
-    // kt - 2, in interval kt - 1) are behind barrier kt; slots kt, kt - 1 (late PV) are being read, slot kt + 1 is landing
-    auto stage = [&](int kt) {
-        const unsigned slot = lds0 + (unsigned)(kt & 3) * 16384u;
-        glds16_buf_asm(rs4, voff_k + kt * tile_bytes, slot + wave * 1024);
-        glds16_buf_asm(rs4, voff_v + kt * tile_bytes, slot + 8192 + wave * 1024);
-    };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_eff = 0.f, l_run = 0.f;
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    const bf16x8 k_one = make_q_ext(1.0f, h);
-    bf16x8 q_ext = make_q_ext(0.f, h);
-    const int tr_grp = (lane >> 4) & 1, tr_i = lane & 15, tr_q = tr_i >> 2, tr_p = tr_i & 3;
-    int tr_off[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const int c = dt * 4 + 2 * tr_grp + (tr_p >> 1);
-        tr_off[dt] = (4 * h + tr_q) * 128 + ((c ^ (((tr_q >> 1) & 1) << 2)) << 4) + (tr_p & 1) * 8;
-    }
-    const int n_tiles = (kv_len + 63) / 64;
-    f32x16 s[2];
-
-    // Lane constants of the LDS fragment addresses.  They are re-declared opaque at the top of every tile (tile_consts): left to
-    // itself hipcc hoists lane constant + immediate for each of the 24 reads of a tile out of the loop as 24 separate registers and
-    // spills them -- and a compiler-counted reload waits for the hand-issued LDS-DMA in flight as well.
-    int k_lane[4];
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) k_lane[ds] = swz128(r32, 2 * ds + h);      // row kb * 32 + r32: + kb * 4096 (the swizzle term does not see kb)
-    int k_cur[4], v_cur[2];
-    auto tile_consts = [&]() {
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds) { k_cur[ds] = k_lane[ds]; asm volatile("" : "+v"(k_cur[ds])); }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) { v_cur[dt] = tr_off[dt]; asm volatile("" : "+v"(v_cur[dt])); }
-    };
-    auto scores = [&](int kt) {                        // S'^T of tile kt into s (log2 domain, shifted by the row reference)
-        const char* sK = smem + (kt & 3) * 16384;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
-#pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const bf16x8 kf = *(const bf16x8*)(sK + k_cur[ds] + kb * 4096);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        const int kbase = kt * 64;
-        if (kbase + 64 > kv_len) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= kv_len) s[kb][r] = NEG_BIG;
-                }
-        }
-    };
-    auto exps = [&]() -> float {
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(s[kb][r]);
-                ps[r & 3] += pv;
-                s[kb][r] = pv;
-            }
-        return (ps[0] + ps[1]) + (ps[2] + ps[3]);
-    };
-    auto cvt_p = [&](bf16x8 (&pf)[4]) {                // P (in s) -> the four bf16 B fragments of PV (k-steps kb*2 + st)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const f32x8 pv = {s[kb][8 * st + 0], s[kb][8 * st + 1], s[kb][8 * st + 2], s[kb][8 * st + 3],
-                                  s[kb][8 * st + 4], s[kb][8 * st + 5], s[kb][8 * st + 6], s[kb][8 * st + 7]};
-                pf[kb * 2 + st] = __builtin_convertvector(pv, bf16x8);
-            }
-    };
-    auto pv_block = [&](int kt, const bf16x8 (&pf)[4]) {
-        const char* sV = smem + (kt & 3) * 16384 + 8192;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const char* a0 = sV + v_cur[dt] + (kb * 32 + 16 * st) * 128;
-                    const char* a1 = a0 + 8 * 128;
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
-                    const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb * 2 + st], o[dt], 0, 0, 0);
-                }
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ONE loop for both halves (two loop bodies side by side cost 73 spilled registers): the halves differ in where the PV block and the
-    // staging of the next tile stand.  early: S E [stage] cvt PV(kt);  late: PV(kt - 1) [stage] S E cvt, P carried across the barrier.
-    stage(0);
-    stage(1);                                                          // n_tiles >= 4 here (a whole 256-row block: kv_len >= 256)
-    bf16x8 pf[4];
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        // tile kt must have landed; tile kt + 1 (this wave's 2 newest LDS-DMA instructions) may stay in flight.  No other vector memory
-        // instruction stands in the loop (no spills: checked in the ISA), so the count is exact.
-        if (kt + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                               // barrier kt
-        tile_consts();
-        if (late) {
-            if (kt > 0) pv_block(kt - 1, pf);                          // V of slot (kt - 1) % 3
-            if (kt + 2 < n_tiles) stage(kt + 2);
-        }
-        // E(kt): speculative against the stale row reference, or the careful pass (first tile / a half-row sum above the bound); a
-        // careful pass rescales O, which holds tiles <= kt - 1 in both halves at this point: the 4-wave kernel's order
-        float psum = 0.f;
-        bool redo = kt == 0;
-        if (!redo) {
-            scores(kt);
-            psum = exps();
-            if (!late && kt + 2 < n_tiles) stage(kt + 2);
-            redo = __any(!(psum <= RESCALE_SUM));
-        }
-        else if (!late && kt + 2 < n_tiles) stage(kt + 2);             // first tile: ahead of the careful pass
-        if (redo) {
-            scores(kt);
-            float mx = s[0][0];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-            mx = half_max(mx);
-            const float m_new = bf16_round(kt == 0 ? mx : m_eff + fmaxf(mx, 0.f));
-            const float d = m_new - m_eff;
-            if (kt != 0) {
-                const float alpha = fast_exp2(-d);
-                l_run *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] -= d;
-            m_eff = m_new;
-            q_ext = make_q_ext(-m_new, h);
-            psum = exps();
-        }
-        l_run += psum;
-        cvt_p(pf);
-        if (!late) pv_block(kt, pf);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                                   // barrier n_tiles: every wave passes n_tiles + 1
-    tile_consts();
-    if (late) pv_block(n_tiles - 1, pf);
-    const float l_tot = half_sum(l_run);
-    const float inv = 1.0f / l_tot;
-    bf16* op = out + (row0 + q0 + r32) * ldo + head * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = dt * 32 + 8 * g + 4 * h;
-            store4<bf16>(op + d0, o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        }
-}
-
-#endif
-
 // ------------------------------------------------------------------------------------ fp32
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const float* __restrict__ qkv, int ld, float* __restrict__ out,
                                                           int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
@@ -776,20 +518,10 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const long long pairs8 = ((long long)a->heads * a->n_seq + 7) / 8;          // (sequence, head) pairs per XCD group
     if (pairs8 * nqb * 8 > 0x7fffffffLL) { *err = "attention: grid too large"; return -22; }
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
-    if (a->dtype == VV_BF16) {
-#if VV_ATTN_W8
-        if (a->seq_n >= 256) {       // whole 256-row blocks: the 8-wave kernel; the rows behind them: the 4-wave kernel in tail mode
-            const dim3 g8((unsigned)(pairs8 * (a->seq_n >> 8) * 8));
-            attn_bf16_w8_kernel<<<g8, 512, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
-                                                    total_rows, a->heads, a->n_seq, a->rope_cs_q);
-            const dim3 gt((unsigned)(pairs8 * 2 * 8));
-            attn_bf16_kernel<<<gt, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                                 a->heads, a->n_seq, a->rope_cs_q, 1);
-        } else
-#endif
+    if (a->dtype == VV_BF16)
         attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                               a->heads, a->n_seq, a->rope_cs_q, 0);
-    } else
+                                               a->heads, a->n_seq, a->rope_cs_q);
+    else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
                                               a->heads, a->n_seq);
     hipError_t he = hipGetLastError();
