@@ -149,8 +149,6 @@ VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the co
  * norm and the SUM rounded to bf16 once, where a row outside the tail is rounded in the GEMM epilogue: a tail row differs from
  * the plain launch by fp32 summation order -- which later bf16 roundings amplify to bf16-level noise, so with the tail on a row's
  * result depends (inside the bf16 tolerance class) on its position in the launch.  Off, it does not; the fp32 path never splits.
- * "row_split" (bf16): 1 (default) = vv_transformer_steps lets the gate-store GEMMs hand the rows of a partial last round of
- * 256 x 256 tiles to the 128 x 128 kernel (vv_gemm_args.row_split; bit-identical, it only changes which kernel computes a row); 0 = off.
  * "rope_q_attn" (bf16): 1 (default) = the query side of the rope is applied by the attention kernel while it loads Q, the QKV GEMM
  * ropes the k columns only; 0 = all of it in the GEMM epilogue (the fp32 model always does).
  * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
@@ -189,9 +187,6 @@ typedef struct vv_gemm_args {
     void* C_tail;              /* tail_parts > 1: fp32 [tail_parts][M - tail_row0][ldc] gated products of the K parts of rows >= tail_row0
                                   (part 0 carries the bias); those rows of C are NOT written: the consumer sums the parts and rounds
                                   the sum to the output dtype once (vv_ln_args.delta_tail) */
-    int32_t row_split;         /* bf16 store / gate-store, persistent kernel: 1 = when the 256 x 256 tile count leaves a partial last round,
-                                  the rows of that round go to the 128 x 128 kernel as a second launch (bit-identical result: the two
-                                  kernels share one arithmetic); 0 = one launch */
     int32_t rope_skip_q;       /* VV_EPI_QKV_ROPE: 1 = leave the q columns [0, rope_dim) un-roped (plain bias + store); the attention
                                   kernel ropes them while it loads Q (vv_attn_args.rope_cs_q).  The k columns are roped as always */
 } vv_gemm_args;

@@ -356,38 +356,6 @@ def test_gemm_headline_shape_every_row(hip_tiny):
             check_rows(got_fn, lambda lo, hi: gate * (A[lo:hi].float() @ Wo.float().t() + bo), so)
 
 
-@pytest.mark.parametrize("K", [1024, 2048])
-def test_gemm_row_split_tail_is_bit_identical(hip_tiny, K):
-    """Round 4: when the 256 x 256 tile count leaves a partial last round of the persistent kernel (M = 102,400, N = 1024: 1,600 tiles =
-    6.25 rounds on 256 CUs), `row_split` hands the rows of that round to the 128 x 128 kernel as a second launch.  The two kernels share
-    one arithmetic, so the result must equal the single launch BIT FOR BIT (gate-store, the out-projection's and FF2's shapes; plain store
-    with tanh-GELU as well) -- unlike the split-K tail this changes which kernel computes a row, never its value."""
-    rt, gu = _imports()
-    eng = hip_tiny["f32"]
-    dev = gu.DEV
-    M, N = 102400, 1024
-    g = torch.Generator().manual_seed(K)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
-    b = (torch.randn(N, generator=g) * 0.1).to(dev)
-    gate = torch.randn(N, generator=g).to(dev)
-    n_cu = torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8
-    assert (M // 256) * (N // 256) % n_cu != 0, "the shape must leave a partial last round on this device"
-    one = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate)
-    two = gu.gemm(eng, A, W, bias=b, mode=3, gate=gate, row_split=1, c_fill=5.0)
-    assert torch.equal(one, two)
-    want = gate * (A[-4096:].float() @ W.float().t() + b)
-    assert gu.rel_err(two[-4096:], want) < TOL_BF16                         # the rows of the second launch, against fp32
-    one = gu.gemm(eng, A, W, bias=b, act=1)
-    two = gu.gemm(eng, A, W, bias=b, act=1, row_split=1, c_fill=5.0)
-    assert torch.equal(one, two)
-    # a shape with whole rounds only is not split (nothing to gain), a ragged M is: the second launch owns the partial last panel
-    Mr = 256 * 390 + 77
-    one = gu.gemm(eng, A[:Mr], W, bias=b, mode=3, gate=gate)
-    two = gu.gemm(eng, A[:Mr], W, bias=b, mode=3, gate=gate, row_split=1, c_fill=5.0)
-    assert torch.equal(one, two)
-
-
 def test_gemm_rejects_bad_shapes(hip_tiny):
     rt, gu = _imports()
     eng = hip_tiny["f32"]

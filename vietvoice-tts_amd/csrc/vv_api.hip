@@ -53,8 +53,6 @@ struct vv_ctx {
                                         // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
-    int row_split = 1;                  // bf16 gate-store GEMMs: 1 = the rows of a partial last round of 256 x 256 tiles go to the 128 x 128 kernel (a second
-                                        // launch; bit-identical: one arithmetic for both kernels), vv_gemm_args.row_split
     int rope_q_attn = 1;                // bf16: 1 = the QKV GEMM ropes the k columns only and the attention kernel ropes Q while loading it
     int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
                                         // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
@@ -149,7 +147,7 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
-         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0, int row_split = 0) {
+         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
@@ -157,7 +155,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
-    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q; g.row_split = row_split;
+    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -577,13 +575,13 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D,
-                             0, nullptr, 0, 0, -1, nullptr, 0, tp_o ? h2_tail : nullptr, tp_o ? tail_row0 : 0, tp_o, 0, c->row_split)) return r;
+                             0, nullptr, 0, 0, -1, nullptr, 0, tp_o ? h2_tail : nullptr, tp_o ? tail_row0 : 0, tp_o)) return r;
             a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
             a.delta = h2; a.delta2 = nullptr; a.keep_x = 1; a.delta_tail_parts = tp_o; a.delta2_tail_parts = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + 2.0 * es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h3, D, (int)R, D, FF, st, mod + 5 * D,
-                             0, nullptr, 0, 0, -1, nullptr, 0, tp_f ? h3_tail : nullptr, tp_f ? tail_row0 : 0, tp_f, 0, c->row_split)) return r;
+                             0, nullptr, 0, 0, -1, nullptr, 0, tp_f ? h3_tail : nullptr, tp_f ? tail_row0 : 0, tp_f)) return r;
             pending = true;
         }
         {
@@ -766,7 +764,6 @@ int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!c || !name) return -22;
     if (!strcmp(name, "rope_rows")) { c->rope_rows = value != 0; return 0; }
     if (!strcmp(name, "rope_q_attn")) { c->rope_q_attn = value != 0; return 0; }
-    if (!strcmp(name, "row_split")) { c->row_split = value != 0; return 0; }
     if (!strcmp(name, "voc_x3_rows")) {
         if (value != 0 && value != 128) return c->fail(-22, "vv_set_option: voc_x3_rows takes 0 (64-row workgroups) or 128");
         c->voc_x3_rows = value; return 0;

@@ -956,43 +956,15 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
     return hipGetLastError();
 }
 
-// Row-split tail (round 4).  One persistent workgroup per CU walks ceil(tiles / n_cu) rounds of 256 x 256 tiles; a tile count that
-// leaves a partial last round (the two N = 1024 GEMMs of the flagship: 1600 tiles = 6.25 rounds) pays a whole round for it.  The
-// rows of that partial round go to the 128 x 128 kernel instead -- a second launch over the last row panels, four times as many
-// workgroups of a quarter of the work each.  Both kernels share one arithmetic (bias-started accumulators, the same K order and MFMA,
-// act_pair / rope_pair), so the result is BIT-IDENTICAL to the single launch: unlike the split-K tail this does not make a row's
-// result depend on its position.  Returns the rows the persistent launch keeps (0 = no split).
-inline int row_split_main_rows(int M, int N, int n_cu, int row_split) {
-    if (!row_split || N % 256 || M < 4096) return 0;
-    const int m_tiles = (M + 255) / 256, n_tiles = N / 256, total = m_tiles * n_tiles;
-    const int rounds = total / n_cu;
-    if (rounds < 1 || total % n_cu == 0) return 0;
-    int main_panels = (int)((long long)rounds * n_cu / n_tiles) / 8 * 8;       // whole rounds = whole panels, in multiples of the 8 XCD labels
-    while (main_panels > 0 && ((long long)main_panels * n_tiles) % n_cu) main_panels -= 8;
-    if (main_panels <= 0) return 0;
-    // worth it only while the 128 x 128 launch is a single round of its own: 4 x the tail tiles on 2 workgroups per CU
-    if ((long long)(m_tiles - main_panels) * n_tiles * 4 > 2LL * n_cu) return 0;
-    return main_panels * 256;
-}
-
 template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
-                  hipStream_t st, int force_tile, int row_split = 0) {
+                  hipStream_t st, int force_tile) {
     const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
     if constexpr (sizeof(T) == 2) {
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
-        if (big && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act)) {
-            if constexpr (MODE == MODE_GATE_STORE || MODE == MODE_STORE) {
-                const int m_main = e.ks > 1 ? 0 : row_split_main_rows(M, N, device_cus(), row_split);
-                if (m_main > 0) {
-                    if (hipError_t he = launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, m_main, N, K, e, st); he != hipSuccess) return he;
-                    return launch_t<T, MODE, To, 0>((const char*)A + (size_t)m_main * lda * sizeof(T), lda, W, ldw,
-                                                    (char*)C + (size_t)m_main * ldc * sizeof(To), ldc, M - m_main, N, K, e, st);
-                }
-            }
+        if (big && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
             return launch_pp<MODE, To>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
-        }
     }
     if (e.ks > 1) return hipErrorInvalidValue;                 // a split-K tail exists in the persistent kernel only (vvk_gemm checks)
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
@@ -1055,7 +1027,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (g->mode == MODE_GATE_RES && g->out_dtype != VV_F32) { *err = "gemm: residual stream is fp32"; return -22; }
     const bool bf = g->dtype == VV_BF16, obf = g->out_dtype == VV_BF16;
     hipError_t he = hipSuccess;
-#define GO(T, MODE, To) he = launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st, g->tile, g->row_split)
+#define GO(T, MODE, To) he = launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st, g->tile)
     if (g->mode == MODE_STORE) {
         if (bf && obf) GO(bf16, MODE_STORE, bf16);
         else if (bf) GO(bf16, MODE_STORE, float);
