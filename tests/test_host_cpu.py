@@ -502,3 +502,19 @@ def test_short_reference_clip_raises_before_anything_runs(cpu_engine, tmp_path):
     assert calls == []                                              # nothing was launched
     assert len(eng._prepare_inputs(clip(n_fft // 2 + 1), "xin chào", "chào bạn")) == 1      # the smallest admitted clip
     eng._synthesize_sessions = orig
+
+
+def test_batching_frontend_close_drains_and_refuses(cpu_engine):
+    """Round 4 (pipelined front end): close() serves what was submitted before it (the sentinel queues up behind the requests; a
+    collected batch is always delivered to the GPU stage), and a request submitted afterwards fails at once instead of hanging."""
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    for overlap in (True, False):
+        fe = BatchingFrontend(cpu_engine, max_wait_ms=1.0, max_requests=2, overlap=overlap)
+        futs = [fe.submit("Xin chào.", speed=1.0, serial=i) for i in range(5)]
+        fe.close()
+        assert all(f.done() for f in futs)
+        outs = [f.result()[0] for f in futs]
+        assert all(o.dtype == np.int16 and o.size > 0 for o in outs) and fe.stats()["requests"] == 5 and fe.stats()["batches"] >= 3
+        late = fe.submit("Xin chào.")
+        with pytest.raises(RuntimeError, match="front end is closed"):
+            late.result(timeout=5)

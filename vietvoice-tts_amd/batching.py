@@ -51,6 +51,7 @@ class BatchingFrontend:
         self._serial = 0
         self._serial_lock = threading.Lock()
         self._stop = False
+        self._closing = False          # the close() sentinel has been taken off the request queue
         self.batches_run = 0
         self.requests_done = 0
         self.chunks_run = 0
@@ -69,6 +70,9 @@ class BatchingFrontend:
         """voice: gender / group / area / emotion / sample_iteration / reference_audio / reference_text.
         ``serial`` fixes the request's noise stream (default: arrival counter)."""
         fut: Future = Future()
+        if self._stop:
+            fut.set_exception(RuntimeError("Speech synthesis failed: the batching front end is closed"))
+            return fut
         with self._serial_lock:
             if serial is None:
                 serial = self._serial
@@ -80,10 +84,19 @@ class BatchingFrontend:
         return self.submit(text, speed, **voice).result()
 
     def close(self):
-        self._stop = True
+        """Drain and stop: requests submitted before the call are still served (the sentinel queues up behind them); a request that
+        could not be (a stage died, the join timed out) gets an exception instead of a Future that never completes."""
         self._q.put(None)
         for t in self._threads:
-            t.join(timeout=60)
+            t.join(timeout=120)
+        self._stop = True
+        while True:
+            try:
+                req = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if req is not None and not req[4].done():
+                req[4].set_exception(RuntimeError("Speech synthesis failed: the batching front end is closed"))
 
     def stats(self) -> dict:
         b = max(self.batches_run, 1)
@@ -117,20 +130,23 @@ class BatchingFrontend:
     def _collect(self) -> Optional[_Batch]:
         """Block for the first request, then take what arrives within ``max_wait`` -- and whatever is ALREADY queued when the window
         closes (the window bounds the wait for arrivals, not the time spent on requests that are there) -- up to ``max_requests``;
-        the host preparation of the collected requests follows."""
+        the host preparation of the collected requests follows.  None = the close() sentinel arrived with nothing collected."""
+        if self._closing:
+            return None
         first = self._q.get()
         if first is None:
+            self._closing = True
             return None
         reqs = [first]
         deadline = time.monotonic() + self.max_wait
-        while len(reqs) < self.max_requests and not self._stop:
+        while len(reqs) < self.max_requests:
             left = deadline - time.monotonic()
             try:
                 nxt = self._q.get(timeout=left) if left > 0 else self._q.get_nowait()
             except queue.Empty:
                 break
             if nxt is None:
-                self._stop = True
+                self._closing = True
                 break
             reqs.append(nxt)
         batch = _Batch()
@@ -139,29 +155,27 @@ class BatchingFrontend:
         return batch
 
     def _prep_loop(self):
-        while not self._stop:
+        while True:
             batch = self._collect()
             if batch is None:
                 break
-            # hand over; while the GPU stage still has a batch waiting in front, keep filling this one
-            while not self._stop:
-                if batch.flat:
-                    try:
-                        self._ready.put(batch, timeout=0.002)
-                        break
-                    except queue.Full:
-                        pass
-                elif batch.n_req == 0:
-                    break                                   # every request of the batch failed in preparation
-                if batch.n_req < self.max_requests:
+            # hand over; while the GPU stage still has a batch waiting in front, keep filling this one (a collected batch is always
+            # delivered, also when close() arrives meanwhile)
+            while batch.flat:
+                try:
+                    self._ready.put(batch, timeout=0.002)
+                    break
+                except queue.Full:
+                    pass
+                if batch.n_req < self.max_requests and not self._closing:
                     try:
                         nxt = self._q.get(timeout=0.002)
                     except queue.Empty:
                         continue
                     if nxt is None:
-                        self._stop = True
-                        break
-                    self._prepare_one(nxt, batch)
+                        self._closing = True
+                    else:
+                        self._prepare_one(nxt, batch)
         self._ready.put(None)
 
     # ------------------------------------------------------------------ stage 2: the GPU
@@ -218,7 +232,7 @@ class BatchingFrontend:
 
     # ------------------------------------------------------------------ overlap=False: the three stages in order on one thread
     def _serial_loop(self):
-        while not self._stop:
+        while True:
             batch = self._collect()
             if batch is None:
                 break
