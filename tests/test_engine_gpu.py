@@ -312,6 +312,27 @@ def test_bench_json_contract():
     assert pi["value"] > 0 and pi["steps"] >= 1 and "H2D" in pi["what"] and "D2H" in pi["what"]
 
 
+def test_bench_serve_workload_contract():
+    """`bench.py --workload serve` (SURVEY 8f N2 measured) stays alive: tiny model, 12 requests from 4 client threads; one JSON line with
+    the serial leg (the reference REST layer's behaviour), the pipelined and the one-thread front end, each with rates, latency
+    percentiles and -- for the front ends -- batch fill and GPU-busy fraction; every request served in every leg."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "serve", "--spec", "tiny", "--nfe", "5", "--dtype", "fp32",
+                        "--requests", "12", "--serial-requests", "4", "--clients", "4", "--batch", "8"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "audio-seconds/sec" and d["value"] == d["frontend_overlapped"]["audio_s_per_s"] > 0 and "serve" in d["config"]["workload"]
+    assert d["serial"]["requests"] == 4 and d["serial"]["latency_p50_ms"] > 0
+    for k in ("frontend_overlapped", "frontend_single_thread"):
+        v = d[k]
+        assert v["requests"] == 12 and v["audio_s_per_s"] > 0 and v["latency_p95_ms"] >= v["latency_p50_ms"] > 0
+        assert 1 <= v["requests_per_batch"] <= 8 and 0 < v["gpu_busy_frac"] <= 1.0 and v["batches"] >= 2
+
+
 def test_bench_two_rank_branch_over_gloo():
     """The N > 1 branch of bench.py (rendezvous, rank-0 weight pack + broadcast, barriers, MAX-over-ranks time, SUM of audio, one
     JSON line on rank 0) kept alive without multi-GPU hardware: two ranks under torch.distributed.run share cuda:0 with
