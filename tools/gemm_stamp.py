@@ -41,6 +41,7 @@ for p in libs:
         if mode == 1:
             a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr()
+            a.rope_skip_q = 1 if os.environ.get("GEMM_STAMP_SKIP_Q") else 0      # round 4: the q columns are roped by the attention kernel
         for _ in range(20):
             assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
         torch.cuda.synchronize()
