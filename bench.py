@@ -369,6 +369,9 @@ def main():
     voc_x3 = a.dtype == "bf16"                       # the bf16 context's default (vv_set_option "voc_x3" -1): vocoder products as 3-way bf16 splits
     for opt in [o for o in os.environ.get("VV_BENCH_OPTIONS", "").split(",") if o]:      # A/B switches of the C ABI, e.g. rope_rows=0
         k, _, v = opt.partition("=")
+        if k == "rope_theta":                            # 0 = read the rope tables instead of computing the angles in the QKV epilogue
+            eng.set_rope_theta(float(v))
+            continue
         eng.set_option(k, int(v))
         if k == "voc_x3" and int(v) >= 0:
             voc_x3 = int(v) == 1

@@ -141,6 +141,13 @@ VV_API int vv_decode_into(vv_ctx* ctx, int B, int N, const float* x, const int32
                    void* stream);
 VV_API uint64_t vv_ws_generation(const vv_ctx* ctx);   /* number of times the context arena has been (re)allocated */
 
+/* Declares that the rope tables handed to vv_transformer_steps are the STANDARD RoPE tables of base `theta` (angle = pos *
+ * theta^(-2i/head_dim); the q tables times head_dim^-0.5) -- which is what vv_preprocess's contract produces.  The bf16 model then
+ * computes the angles in the QKV GEMM's epilogue instead of reading the tables (vv_gemm_args.rope_theta) and hands the softmax scale to
+ * the attention kernel (vv_attn_args.q_scale).  theta = 0 (the default of a new context): the tables are read.  The fp32 model always
+ * reads them. */
+VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
+
 /* Context switches (explicit API, never the environment).  "fuse_mrf": run the MRF resblock pairs of the C <= 64 vocoder
  * stages through vv_mrf_resblock's fused kernel -- 0 never (two vv_conv1d launches per pair), 1 always, 2 (default) for
  * decodes of <= 8 items, where the stage is launch-bound.  Results are bit-identical either way.
@@ -187,6 +194,11 @@ typedef struct vv_gemm_args {
     void* C_tail;              /* tail_parts > 1: fp32 [tail_parts][M - tail_row0][ldc] gated products of the K parts of rows >= tail_row0
                                   (part 0 carries the bias); those rows of C are NOT written: the consumer sums the parts and rounds
                                   the sum to the output dtype once (vv_ln_args.delta_tail) */
+    float rope_theta;          /* VV_EPI_QKV_ROPE, bf16: > 0 = the tables are the standard RoPE tables of this base (angle = pos * theta^(-2i/64)):
+                                  the epilogue COMPUTES cos / sin of the q and k columns (v_exp / v_fract / v_sin / v_cos on the position: no
+                                  table load behind the stores, the costliest part of the rope epilogue) and applies NO softmax scale to q
+                                  (vv_attn_args.q_scale carries it); angle accurate to ~3e-4 rad at position 4096 -- a tenth of a bf16
+                                  rounding of the roped value.  0 = read the tables (always in fp32) */
     int32_t rope_skip_q;       /* VV_EPI_QKV_ROPE: 1 = leave the q columns [0, rope_dim) un-roped (plain bias + store); the attention
                                   kernel ropes them while it loads Q (vv_attn_args.rope_cs_q).  The k columns are roped as always */
 } vv_gemm_args;
@@ -208,6 +220,8 @@ typedef struct vv_attn_args {
                                   default s * seq_n (padded layout, rows beyond kv_len are computed and ignored) */
     int32_t total_rows;        /* rows in the qkv / out buffers (bounds the K/V buffer resource; reads past it return zero).
                                   Required (> 0) with row_start; 0 = n_seq * seq_n in the padded layout */
+    float q_scale;             /* bf16 kernel: factor applied to q while it is loaded (the softmax scale when the projection did not carry
+                                  it: vv_gemm_args.rope_theta); 0 = 1.0 */
     const float* rope_cs_q;    /* optional (bf16 kernel): compact [seq_n][64] (cos, sin) pair table of the QUERY side (vv_rope_compact of
                                   the q tables, which carry the softmax scale): the q columns arrive un-roped (vv_gemm_args.rope_skip_q)
                                   and are roped here, position = row inside the sequence, in fp32 before the one rounding to bf16 the

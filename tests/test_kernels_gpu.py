@@ -497,6 +497,67 @@ def test_query_rope_in_attention_equals_rope_in_the_gemm(hip_tiny, M_seq, tile):
         gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
 
 
+def test_computed_rope_matches_the_tables(hip_tiny):
+    """Round 4: with the standard tables declared (vv_gemm_args.rope_theta / vv_set_rope_theta) the bf16 QKV epilogue COMPUTES cos / sin
+    of the q and k columns from the position (v_exp / v_fract / v_cos / v_sin: no table load behind the stores) and leaves the softmax
+    scale to the attention kernel (vv_attn_args.q_scale).  Against an fp32 projection roped with float64-defined tables: bf16 tolerance at
+    positions up to 4,095 (where an fp32 angle is ~3e-4 rad off); the 128 x 128 and the persistent kernel give IDENTICAL bits (one
+    formula: an item in a batch equals the item alone); per-row position tables (packed rows) and the table-free uniform form agree;
+    attention with q_scale equals attention on a q that carried the scale."""
+    rt, gu = _imports()
+    from oracle.vv_oracle import Oracle
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    seq_n, heads, theta = 4096, 2, 10000.0
+    D = heads * 64
+    M = 2 * seq_n
+    g = torch.Generator().manual_seed(4096)
+    A = torch.randn(M, 256, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(3 * D + 128, 256, generator=g) / 16.0).to(torch.bfloat16).to(dev)          # N = 512: a multiple of the 256 tile
+    b = (torch.randn(3 * D + 128, generator=g) * 0.1).to(dev)
+    inv = 1.0 / (theta ** (torch.arange(0, 64, 2, dtype=torch.float64) / 64))
+    ang = torch.repeat_interleave(torch.arange(seq_n, dtype=torch.float64)[:, None] * inv[None, :], 2, dim=1)
+    cos, sin = ang.cos().float(), ang.sin().float()
+    ropes = [t.contiguous().to(dev) for t in (cos * 0.125, sin * 0.125, cos, sin)]
+    pos = (torch.arange(M, dtype=torch.int32) % seq_n).to(dev)
+    y = (A.float() @ W.float().t() + b).cpu()
+    idx = torch.arange(M) % seq_n
+    want = y.clone()
+    want[:, :D] = Oracle.rope_apply(y[:, :D].reshape(M, heads, 64), cos[idx], sin[idx]).reshape(M, D)            # q: NO scale
+    want[:, D:2 * D] = Oracle.rope_apply(y[:, D:2 * D].reshape(M, heads, 64), cos[idx], sin[idx]).reshape(M, D)
+    outs = {}
+    for tile in (128, 256):
+        for with_pos in (False, True):
+            got = gu.gemm(eng, A, W, bias=b, mode=1, ropes=ropes, seq_n=seq_n, rope_dim=D, tile=tile, rope_theta=theta,
+                          rope_pos=pos if with_pos else None)
+            outs[(tile, with_pos)] = got
+            err = gu.rel_err(got, want)
+            hi = float((got[-64:, :2 * D].float().cpu() - want[-64:, :2 * D]).abs().max() / want[:, :2 * D].abs().max())
+            print(f"\n[computed rope, tile {tile}, pos table {with_pos}] rel err {err:.2e}; rows at positions 4032..4095: {hi:.2e}")
+            assert err < TOL_BF16
+    assert torch.equal(outs[(128, False)], outs[(256, False)]) and torch.equal(outs[(128, True)], outs[(256, True)])
+    assert torch.equal(outs[(256, False)], outs[(256, True)])
+    tab = gu.gemm(eng, A, W, bias=b, mode=1, ropes=ropes, seq_n=seq_n, rope_dim=D, tile=256)          # the table form (q carries 0.125)
+    dk = float((tab[:, D:2 * D].float() - outs[(256, False)][:, D:2 * D].float()).abs().max() / want[:, D:2 * D].abs().max())
+    print(f"[computed rope] k columns, computed vs table form: max diff {dk:.2e} of the range (bf16 ulp = 3.9e-3)")
+    assert dk < 8e-3
+    # attention: q_scale on an unscaled q == the same q pre-scaled by an exact power of two
+    qkv = outs[(256, False)][:seq_n, : 3 * D].contiguous()
+    kv = torch.tensor([seq_n], dtype=torch.int32, device=dev)
+
+    def attention(x, q_scale):
+        out = torch.zeros(seq_n, D, dtype=torch.bfloat16, device=dev)
+        a = rt.vv_attn_args()
+        a.dtype, a.qkv, a.ld_qkv, a.out, a.ld_out = rt.VV_BF16, x.data_ptr(), 3 * D, out.data_ptr(), D
+        a.n_seq, a.seq_n, a.heads, a.dim, a.kv_len, a.q_scale = 1, seq_n, heads, D, kv.data_ptr(), q_scale
+        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
+        torch.cuda.synchronize()
+        return out
+    pre = qkv.clone()
+    pre[:, :D] = (pre[:, :D].float() * 0.125).to(torch.bfloat16)                 # exact in bf16
+    assert torch.equal(attention(qkv, 0.125), attention(pre, 0.0))
+
+
 def test_attention_spiked_max(hip_tiny):
     """Online-softmax rescale branch: a key late in the sequence dominates one query row."""
     rt, gu = _imports()

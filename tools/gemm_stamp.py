@@ -42,6 +42,7 @@ for p in libs:
             a.cos_q = a.sin_q = a.cos_k = a.sin_k = cs.data_ptr(); a.seq_n, a.rope_dim = 1600, 1024
             a.rope_cs_q = a.rope_cs_k = cs.data_ptr()
             a.rope_skip_q = 1 if os.environ.get("GEMM_STAMP_SKIP_Q") else 0      # round 4: the q columns are roped by the attention kernel
+            a.rope_theta = float(os.environ.get("GEMM_STAMP_THETA", "0"))         # round 4: > 0 = cos / sin computed in the epilogue (no tables)
         for _ in range(20):
             assert e.lib.vv_gemm(e.ctx, C.byref(a), st) == 0, e.lib.vv_last_error(e.ctx)
         torch.cuda.synchronize()

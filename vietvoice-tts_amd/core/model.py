@@ -83,6 +83,15 @@ class HipSession:
                    "rope_cos_k": up(vals[3]).reshape(n, -1), "rope_sin_k": up(vals[4]).reshape(n, -1),
                    "cat_mel_text": up(vals[5]), "cat_mel_text_drop": up(vals[6]),
                    "seq_len": torch.tensor([n], dtype=torch.int32, device=dev)}
+            # The bf16 model computes the standard rope angles instead of reading the tables (vv_set_rope_theta).  This session takes
+            # its tables from the CALLER (the reference's I/O contract, core/tts_engine.py:161-170): if they are not the standard ones
+            # this engine produces in its preprocess stage, fall back to reading them -- never ignore what was fed.
+            if not getattr(self, "_rope_checked", False):
+                same = all(torch.equal(pre[k_], eng.rope[i][:n]) for i, k_ in enumerate(("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k")))
+                if not same:
+                    logger.warning("transformer session: non-standard rope tables fed; the tables are read instead of computed")
+                    eng.set_rope_theta(0.0)
+                self._rope_checked = True
             step = int(np.asarray(vals[7]).reshape(-1)[0])
             k = min(self.fuse_nfe, eng.n_steps - step)
             eng.transformer_steps(x, pre, step, k)

@@ -53,6 +53,9 @@ struct vv_ctx {
                                         // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
+    float rope_theta = 0.f;             // > 0 (vv_set_rope_theta): the caller's rope tables are the standard ones of this base; the bf16 QKV epilogue then
+                                        // computes cos / sin from the position (no table load), q leaves the GEMM without the softmax scale and the
+                                        // attention kernel applies it (q_scale).  Overrides rope_q_attn.
     int rope_q_attn = 1;                // bf16: 1 = the QKV GEMM ropes the k columns only and the attention kernel ropes Q while loading it
     int voc_x3 = -1;                    // vocoder conv products: 0 = v_mfma_f32_32x32x2_f32, 1 = exact 3-way bf16 split on the bf16 matrix pipe
                                         // (vv_vocoder_x3.hip: six piece products, fp32 accumulate, fp32 fidelity); -1 = by acoustic dtype (bf16
@@ -147,7 +150,7 @@ struct Need { size_t b = 0; void add(size_t bytes) { b = align_up(b, 256) + byte
 int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, int lda, const char* wname, int ldw, const char* bname,
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
-         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0) {
+         int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0, float rope_theta = 0.f) {
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
@@ -155,7 +158,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     g.bias = bname ? c->Wf(bname) : nullptr; g.gate = gate; g.n_store = n_store; g.seq_n = seq_n; g.rope_dim = rope_dim;
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
-    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q;
+    g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q; g.rope_theta = rope_theta;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
@@ -521,7 +524,8 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     const int* qkv_pos = uniform ? nullptr : row_pos;
     // bf16: the query side of the rope moves from the QKV GEMM's epilogue into the attention kernel's Q load (option "rope_q_attn",
     // default on; profiles/r04/attention_notes.md); the fp32 (numerics) path keeps all of it in the GEMM
-    const int q_rope_attn = (c->rope_q_attn && c->dt == VV_DTYPE_BF16) ? 1 : 0;
+    const float rope_theta = c->dt == VV_DTYPE_BF16 ? c->rope_theta : 0.f;        // computed rope: both q and k in the GEMM epilogue, scale in attention
+    const int q_rope_attn = (c->rope_q_attn && c->dt == VV_DTYPE_BF16 && !(rope_theta > 0.f)) ? 1 : 0;
 
     KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
     {
@@ -566,11 +570,12 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
             a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
             { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
             if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, qkv_pos, c->rope_rows,
-                             nullptr, 0, 0, q_rope_attn)) return r;
+                             nullptr, 0, 0, q_rope_attn, rope_theta)) return r;
             {
                 vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
                 t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
                 t.rope_cs_q = q_rope_attn ? csq : nullptr;
+                t.q_scale = rope_theta > 0.f ? 1.0f / sqrtf((float)g.head_dim) : 0.f;
                 Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
                 KCHK(c, vvk_attention(&t, st, &m__));
             }
@@ -757,6 +762,13 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
         KCHK(c, vvk_conv_post(cur, c->Wf("voc.post.weight"), c->post_bias, pcm, ld_pcm, wave_f32, B, C, T, g.voc_post_k, 0.01f,
                               lens + (size_t)nu * B, st, &m__));
     }
+    return 0;
+}
+
+int vv_set_rope_theta(vv_ctx* c, float theta) {
+    if (!c) return -22;
+    if (theta != 0.f && !(theta > 1.f)) return c->fail(-22, "vv_set_rope_theta: the base must be > 1 (0 = read the tables)");
+    c->rope_theta = theta;
     return 0;
 }
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
                                                            const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
-                                                           const float* __restrict__ rope_cs_q) {
+                                                           const float* __restrict__ rope_cs_q, float q_mul) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
     const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
     if (!blk.valid) return;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * LOG2E);     // scores in the log2 domain: p = exp2(s)
+            for (int j = 0; j < 8; ++j) qf[ds][j] = (bf16)((float)qf[ds][j] * q_mul);     // scores in the log2 domain: p = exp2(s); q_mul = log2(e) x q_scale
         }
     }
 
@@ -520,7 +520,7 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
     if (a->dtype == VV_BF16)
         attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                               a->heads, a->n_seq, a->rope_cs_q);
+                                               a->heads, a->n_seq, a->rope_cs_q, LOG2E * (a->q_scale > 0.f ? a->q_scale : 1.0f));
     else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
                                               a->heads, a->n_seq);

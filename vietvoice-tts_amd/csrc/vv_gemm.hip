@@ -54,6 +54,7 @@ struct EpiArgs {
     int cs_by_row;           // cs_q / cs_k are [M][64] tables already gathered per ROW (vv_rope_rows): no position lookup in the epilogue
     int rope_dim;
     int rope_lo;             // first roped column: 0, or rope_dim when the q columns are roped by the attention kernel (rope_skip_q)
+    float rope_k1, rope_k0;  // computed rope (rope_k1 > 0): revolutions per position of pair i = exp2(-(i * rope_k1 + rope_k0)), k1 = log2(theta) / 32, k0 = log2(2 pi)
 #ifdef VV_GEMM_EXP           // diagnostic build only (profiles/r04/gemm_notes.md)
     int n_group;             // persistent kernel: walk the n-tiles in groups of n_group (each XCD finishes all its panels for one group of
                              // weight tiles before the next group: the group's weights stay in that XCD's L2); 0 = all n-tiles of a panel together
@@ -98,6 +99,16 @@ __device__ __forceinline__ void rope_pair(float& a, float& b, float c, float sn)
     const float nb = __builtin_fmaf(b, c, a * sn);
     a = na; b = nb;
 }
+// The same with cos / sin COMPUTED from the position (bf16 model, standard tables: vv_gemm_args.rope_theta): pair i of a head turns by
+// pos * theta^(-i/32) rad.  In revolutions: pos * exp2(-(i k1 + k0)), fract, v_cos / v_sin (their argument is in revolutions) -- six
+// vector instructions instead of a table load whose in-order wait stands behind the previous pass's stores (the rope epilogue was
+// 3-6 x a plain one: profiles/r04/gemm_notes.md).  fp32 angle: ~3e-4 rad off at position 4096 for pair 0, geometrically less for
+// the others -- a tenth of the bf16 rounding the roped value gets anyway.  One formula for both kernels.
+__device__ __forceinline__ void rope_pair_computed(float& a, float& b, int pos, int pair, float k1, float k0) {
+    const float rev = (float)pos * __builtin_amdgcn_exp2f(-__builtin_fmaf((float)pair, k1, k0));
+    const float fr = __builtin_amdgcn_fractf(rev);
+    rope_pair(a, b, __builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
+}
 
 template <int MODE, typename To>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int m, int pos, int n0, float v0, float v1,
@@ -111,10 +122,15 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
         if (n0 >= e.rope_lo && n0 < 2 * e.rope_dim) {
             const bool is_k = n0 >= e.rope_dim;
             const int d = n0 & 63;
-            const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);       // pair-duplicated tables: c.x == c.y
-            const float4 s = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
-            rope_pair(v0, v1, c.x, s.x);
-            rope_pair(v2, v3, c.z, s.z);
+            if (e.rope_k1 > 0.f) {
+                rope_pair_computed(v0, v1, pos, d >> 1, e.rope_k1, e.rope_k0);
+                rope_pair_computed(v2, v3, pos, (d >> 1) + 1, e.rope_k1, e.rope_k0);
+            } else {
+                const float4 c = *(const float4*)((is_k ? e.cos_k : e.cos_q) + (size_t)pos * 64 + d);       // pair-duplicated tables: c.x == c.y
+                const float4 s = *(const float4*)((is_k ? e.sin_k : e.sin_q) + (size_t)pos * 64 + d);
+                rope_pair(v0, v1, c.x, s.x);
+                rope_pair(v2, v3, c.z, s.z);
+            }
         }
         store4<To>(C + (size_t)m * ldc + n0, v0, v1, v2, v3);
     } else {   // MODE_GATE_RES: C is the fp32 residual stream, updated in place
@@ -733,14 +749,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                     // With row-gathered tables (cs_by_row) the address depends on m alone: no position load, no second wait; the
                     // v columns (a third of the tiles) touch neither.
                     float4 cs4[2][2];
-                    bool do_rope = false;
+                    bool do_rope = false, rope_tile = false;
                     int pos = 0;
                     if constexpr (MODE == MODE_QKV_ROPE) {
-                        const bool rope_tile = bn + wc * 64 < 2 * e.rope_dim && bn + wc * 64 >= e.rope_lo;
-                        do_rope = rope_tile && e.cs_q != nullptr;
+                        rope_tile = bn + wc * 64 < 2 * e.rope_dim && bn + wc * 64 >= e.rope_lo;
+                        do_rope = rope_tile && e.cs_q != nullptr && !(e.rope_k1 > 0.f);
                         if (rope_tile) {
                             const int mc = min(m, M - 1);
-                            if (e.cs_by_row) pos = mc;
+                            if (e.cs_by_row && !(e.rope_k1 > 0.f)) pos = mc;
                             else if (e.pos_tab) pos = e.pos_tab[mc];
                             else {                                     // uniform sequences: m mod seq_n by reciprocal multiply, no load
                                 pos = mc - (int)__umulhi((unsigned)mc, e.seq_rcp) * e.seq_n;
@@ -768,6 +784,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16* __restrict_
                                     rope_pair(a0, a1, t.x, t.y);
                                     rope_pair(a2, a3, t.z, t.w);
                                     v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+                                } else if (e.rope_k1 > 0.f) {
+                                    if (rope_tile) {                    // computed angles: no load at all in this epilogue
+                                        float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                                        rope_pair_computed(a0, a1, pos, nl >> 1, e.rope_k1, e.rope_k0);
+                                        rope_pair_computed(a2, a3, pos, (nl >> 1) + 1, e.rope_k1, e.rope_k0);
+                                        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+                                    }
                                 } else {
                                 const int n0 = bn + wc * 64 + nl;
                                 if (n0 >= e.rope_lo && n0 < 2 * e.rope_dim) {
@@ -1010,6 +1033,10 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
         e.c_part = (char*)g->C_tail; e.tail_panel0 = row0 / 256; e.ks = parts;
     }
     e.rope_dim = g->rope_dim; e.rope_lo = g->rope_skip_q ? g->rope_dim : 0; e.pos_tab = g->rope_pos;
+    if (g->mode == MODE_QKV_ROPE && g->rope_theta > 0.f && g->dtype == VV_BF16) {
+        e.rope_k1 = log2f(g->rope_theta) / 32.0f; e.rope_k0 = 2.6514961294723187f;        // log2(2 pi)
+        if (!(e.rope_k1 > 0.f)) { *err = "gemm: rope_theta must be > 1"; return -22; }
+    }
 #ifdef VV_GEMM_EXP
     e.n_group = 0; e.a_nt = 0;
     // Diagnostic build ONLY (tools/build_variants.py vv_gemm exp=-DVV_GEMM_EXP): the walk / cache-hint experiment of profiles/r04/gemm_notes.md,

@@ -51,13 +51,13 @@ class vv_gemm_args(C.Structure):
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
                 ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32),
-                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p), ("rope_skip_q", C.c_int32)]
+                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p), ("rope_theta", C.c_float), ("rope_skip_q", C.c_int32)]
 
 
 class vv_attn_args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("qkv", C.c_void_p), ("ld_qkv", C.c_int32), ("out", C.c_void_p), ("ld_out", C.c_int32),
                 ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p),
-                ("row_start", C.c_void_p), ("total_rows", C.c_int32), ("rope_cs_q", C.c_void_p)]
+                ("row_start", C.c_void_p), ("total_rows", C.c_int32), ("q_scale", C.c_float), ("rope_cs_q", C.c_void_p)]
 
 
 class vv_ln_args(C.Structure):
@@ -116,6 +116,7 @@ EXPORTS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vv_ws_generation": (C.c_uint64, [C.c_void_p]),
     "vv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "vv_set_rope_theta": (C.c_int, [C.c_void_p, C.c_float]),
     "vv_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "vv_prof_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vv_gemm": (C.c_int, [C.c_void_p, C.POINTER(vv_gemm_args), C.c_void_p]),
@@ -234,6 +235,9 @@ class HipSynth:
         self._check(self.lib.vv_finalize_weights(self.ctx))
         cq, sq, ck, sk = pack.rope_tables(spec)
         self.rope = tuple(t.to(self.device) for t in (cq, sq, ck, sk))
+        # the tables this engine hands to the transformer stage are the standard ones of spec.rope_theta: the bf16 model may compute the
+        # angles in the QKV epilogue instead of reading them (vv_set_rope_theta; the fp32 model reads the tables either way)
+        self._check(self.lib.vv_set_rope_theta(self.ctx, float(spec.rope_theta)))
         self.nfe_step = None
         self.set_nfe(nfe_step)
 
@@ -402,6 +406,11 @@ class HipSynth:
             self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, x.numel(), stats.data_ptr(),
                                                     out.data_ptr(), self._stream()))
         return out
+
+    def set_rope_theta(self, theta: float):
+        """theta > 1: the rope tables of this engine are the standard ones of that base, the bf16 QKV epilogue computes the angles;
+        0: the tables are read (vv_set_rope_theta)."""
+        self._check(self.lib.vv_set_rope_theta(self.ctx, float(theta)))
 
     def set_option(self, name: str, value: int):
         """Context switches of the C ABI (vv_set_option), e.g. ``fuse_mrf`` 0/1."""
