@@ -566,7 +566,12 @@ def test_attention_spiked_max(hip_tiny):
     g = torch.Generator().manual_seed(11)
     qkv = torch.randn(seq_n, 3 * D, generator=g) * 0.3
     qkv[5, :64] = 3.0
-    qkv[200, D:D + 64] = 3.0      # q5 . k200 = 576 >> everything else
+    qkv[200, D:D + 64] = 3.0      # q5 . k200 = 576 >> everything else: 2^831 overflows -> the careful path centres the row
+    # round 4 (no reference until a row needs one): a row whose FIRST tile underflows entirely (q7 . k_j = -576 for every key of tile 0 but
+    # one) must take the careful path there and centre DOWN, then move up again when the ordinary keys of the later tiles arrive
+    qkv[7, :64] = 3.0
+    qkv[:64, D:D + 64] = -3.0
+    qkv[20, D:D + 64] = torch.randn(64, generator=g) * 0.3
     for dtype in (torch.float32, torch.bfloat16):
         x = qkv.to(dtype)
         out = torch.zeros(seq_n, D, dtype=dtype, device=gu.DEV)

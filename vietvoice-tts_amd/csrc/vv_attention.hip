@@ -18,7 +18,12 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_SUM = 256.0f;          // bf16 kernel: a half-row sum of p above 2^8 sends the tile to the careful path
+// bf16 kernel: the exponentials are taken against a row reference that is ZERO until a row needs one (round 4): p = 2^s' is a
+// floating-point value either way -- bf16 / fp32 hold 2^64 as precisely as 1.0 -- so a reference only has to keep p inside the
+// exponent range.  A half-row sum above 2^64 (or inf / nan) on any tile, or a whole-row sum below 2^-64 on the FIRST tile (nothing
+// accumulated yet: every score far below zero), sends the tile to the careful path, which centres the row on its maximum.
+constexpr float RESCALE_SUM = 1.8446744073709552e19f;      // 2^64
+constexpr float TINY_SUM = 5.421010862427522e-20f;         // 2^-64
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // max / sum across the two 32-lane halves with the gfx950 half swap (one v_permlane32_swap instead of a ds_bpermute round trip)
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_eff = 0.f, l_run = 0.f;              // m_eff: row reference in the log2 domain, bf16-representable
+    bool has_ref = false;                        // wave-uniform: some row of this wave has a non-zero reference (the scores then need the shift)
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -228,13 +234,24 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
             return;
 #endif
             __builtin_amdgcn_s_setprio(1);
+            if (has_ref) {                       // rare: a row of this wave is centred on a reference: the shift rides as a 65th contraction element
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
+                for (int kb = 0; kb < 2; ++kb) {
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_one, q_ext, zero16, 0, 0, 0);
 #pragma unroll
-                for (int ds = 0; ds < 4; ++ds) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+                    for (int ds = 0; ds < 4; ++ds) {
+                        const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kb], 0, 0, 0);
+                    }
+                }
+            } else {                             // the common case: no reference anywhere in the wave, 8 MFMAs instead of 10
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int ds = 0; ds < 4; ++ds) {
+                        const bf16x8 kf = *(const bf16x8*)(sK + swz128(kb * 32 + r32, 2 * ds + h));
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], ds == 0 ? zero16 : s[kb], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -262,26 +279,24 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 }
             return (ps[0] + ps[1]) + (ps[2] + ps[3]);
         };
-        // Online softmax with a SPECULATIVE tile: the exponentials are taken against the stale reference m_eff without looking
-        // for the row max first (21 VALU instructions per tile); the partial row sums then tell whether that was safe -- an
-        // element above 2^8 (or an overflow to inf) puts its half-row sum above 256.  Only then (and on the first tile) the
-        // tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the MFMA
-        // subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
-        // which path ran.
+        // Online softmax with a SPECULATIVE tile: the exponentials are taken against the current reference m_eff (zero until a
+        // row needs one) without looking for the row max first (21 VALU instructions per tile); the partial row sums then tell
+        // whether that was safe -- an element above 2^64 (or an overflow to inf) puts its half-row sum above the bound.  Only
+        // then the tile is redone the careful way: scores again, row max, reference moved (kept bf16-representable so that the
+        // MFMA subtracts it exactly), O and l rescaled.  Softmax is invariant to the reference, so results do not depend on
+        // which path ran, beyond the bf16 rounding of P.  (Rounds 1-3 centred every row on its first tile's maximum: one careful
+        // pass per workgroup and 2 of 18 MFMAs per tile for a shift that random or trained logits never need.)
         float psum = 0.f;
-        bool redo = kt == 0;
+        bool redo = false;
 #if VV_ATTN_ABLATE == 1 || VV_ATTN_ABLATE == 3
-        redo = false;
         scores();
         if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
 #else
-        if (!redo) {
-            scores();
-            psum = exps();
-            if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-            redo = __any(!(psum <= RESCALE_SUM));
-        }
-        else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);      // first tile: ahead of the careful path
+        scores();
+        psum = exps();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
+        redo = __any(!(psum <= RESCALE_SUM));
+        if (kt == 0) redo = redo || __any(!(half_sum(psum) >= TINY_SUM));      // first tile: a row whose every weight underflowed needs its own reference
         if (redo) {
             scores();
             float mx = s[0][0];
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
             mx = half_max(mx);                        // the other half-wave holds the other 32 keys of the same query
-            const float m_new = bf16_round(kt == 0 ? mx : m_eff + fmaxf(mx, 0.f));
+            const float m_new = bf16_round(m_eff + (kt == 0 ? mx : fmaxf(mx, 0.f)));      // first tile: centre on the row max, up or down
             const float d = m_new - m_eff;                     // exact: both are bf16 values
             if (kt != 0) {                                     // O and l are zero on the first tile
                 const float alpha = fast_exp2(-d);
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
                 for (int r = 0; r < 16; ++r) s[kb][r] -= d;    // this tile was shifted by the old reference
             m_eff = m_new;
             q_ext = make_q_ext(-m_new, h);
+            has_ref = true;
             psum = exps();
         }
 #endif
