@@ -366,6 +366,7 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None           # includes rank 0's pack + H2D
     eng = HipSynth(spec, None, device=str(device), acoustic_dtype=a.dtype, nfe_step=a.nfe, flat_weights=flat)
+    lanes_opt = 0                                    # vv_set_option "lanes": 0 = auto (two lanes from 65,536 packed rows), 1 = one, 2 = two
     voc_x3 = a.dtype == "bf16"                       # the bf16 context's default (vv_set_option "voc_x3" -1): vocoder products as 3-way bf16 splits
     for opt in [o for o in os.environ.get("VV_BENCH_OPTIONS", "").split(",") if o]:      # A/B switches of the C ABI, e.g. rope_rows=0
         k, _, v = opt.partition("=")
@@ -373,6 +374,8 @@ def main():
             eng.set_rope_theta(float(v))
             continue
         eng.set_option(k, int(v))
+        if k == "lanes":
+            lanes_opt = int(v)
         if k == "voc_x3" and int(v) >= 0:
             voc_x3 = int(v) == 1
     if os.environ.get("VV_BENCH_DUMP_MAPS"):          # diagnostics for profiler-side crashes: the loaded images, so a raw stack can be symbolised
@@ -471,9 +474,14 @@ def main():
         return
 
     # ---- per-kernel-class timing with HIP events on the launch stream (one extra, untimed pass)
+    # The timed steps run the Euler loop as two half batches on two streams (option "lanes": one lane's kernel tails are filled by the
+    # other's kernels).  A kernel's own rate is measured with the chip to itself: the profiled pass runs ONE lane, so the class times
+    # below are each kernel alone and their sum exceeds the two-lane step time by what the overlap recovers.
     eng.prof_enable(True)
     was_graph, a.graph_steps = a.graph_steps, False       # events cannot be recorded inside a replayed graph: the profiled pass runs eagerly
+    eng.set_option("lanes", 1)
     step()
+    eng.set_option("lanes", lanes_opt)
     a.graph_steps = was_graph
     prof = eng.prof_collect()
     eng.prof_enable(False)
@@ -547,6 +555,8 @@ def main():
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
         "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
     }
+    res["lanes"] = {"option": lanes_opt, "what": "Euler steps of a batch with >= 65,536 packed rows run as two half batches on two HIP streams (bit-identical "
+                    "results; tests/test_e2e_gpu.py::test_two_lanes_equal_one_lane_bit_for_bit); kernel_classes / rooflines: one-lane pass, each kernel alone"}
     if pcie_inclusive is not None:
         res["pcie_inclusive"] = pcie_inclusive
     res["devices"] = devices

@@ -158,7 +158,14 @@ VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
  * result depends (inside the bf16 tolerance class) on its position in the launch.  Off, it does not; the fp32 path never splits.
  * "rope_q_attn" (bf16): 1 (default) = the query side of the rope is applied by the attention kernel while it loads Q, the QKV GEMM
  * ropes the k columns only; 0 = all of it in the GEMM epilogue (the fp32 model always does).
- * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up. */
+ * "rope_rows": 1 gathers the compact rope tables per packed row once per call (vv_rope_rows); 0 (default) looks positions up.
+ * "lanes": vv_transformer_steps* runs a batch of >= 2 items as TWO half batches on two HIP streams -- lane 0 on the caller's stream,
+ * lane 1 on a context-owned stream forked from it at the start of the call and joined to it before the call returns (so the call
+ * keeps its stream semantics, and can be captured into a hipGraph) -- so that one lane's kernel tails and launch gaps are filled by
+ * the other's kernels.  0 (default) = for the bf16 model from 2,560 packed rows (2 x sum of the lengths) on, 1 = never, 2 = whenever
+ * the batch has two items.  Results are bit-identical: every item's arithmetic is independent of its batch.
+ * "pp_min_tiles": -1 (default) = vv_gemm's own choice between its persistent 256 x 256 kernel and the 128 x 128 one; n >= 0 = the
+ * persistent kernel for every bf16 GEMM of the path with M >= 4096, N % 256 == 0 and >= n 256-tiles.  Same bits either way. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 
 /* ---- profiling (HIP events on the launch stream, per kernel class) ------------------------- */
@@ -186,7 +193,8 @@ typedef struct vv_gemm_args {
     const float *bias, *gate, *cos_q, *sin_q, *cos_k, *sin_k;
     int32_t n_store, seq_n, rope_dim;
     const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
-    int32_t tile;   /* 0 = auto (256x256 tile when M >= 4096 and N % 256 == 0), 128 or 256 to force */
+    int32_t tile;   /* 0 = auto (bf16: the persistent 256x256 kernel when M >= 4096, N % 256 == 0 and the shape has at least one round of
+                       256-tiles for the chip's CUs or N >= 3072; fp32: 256x256 when M >= 4096 and N % 256 == 0), 128 or 256 to force */
     const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
     int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
                                   needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */

@@ -246,6 +246,8 @@ def test_bf16_pipeline_through_the_persistent_gemm(hip_tiny):
     w = make_synthetic_weights(spec, seed=4242)
     orc = Oracle(spec, w, nfe_step=4)
     eng = HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=4)
+    eng.set_option("pp_min_tiles", 0)      # a small model's GEMMs have far fewer 256-tiles than the chip has CUs: take the persistent kernel anyway
+    eng.set_option("lanes", 1)             # ... with the whole batch in one launch (two lanes of ~2,400 rows would fall under 4096)
     la = [256 * 60, 256 * 45 + 17, 256 * 70, 256 * 52]
     gf = [560, 520, 470, 540]
     batch = make_batch(spec, la, [40, 33, 47, 38], gf, seed=77)
@@ -274,6 +276,8 @@ def test_bf16_item_in_a_batch_equals_the_item_alone_across_gemm_kernels():
     spec = ModelSpec.small()
     w = make_synthetic_weights(spec, seed=4242)
     eng = HipSynth(spec, w, acoustic_dtype="bf16", nfe_step=6)
+    eng.set_option("pp_min_tiles", 0)      # the packed batch on the persistent kernel although a small model has few 256-tiles
+    eng.set_option("lanes", 1)
     la = [256 * 60, 256 * 45 + 17, 256 * 70, 256 * 52]
     lt = [40, 33, 47, 38]
     gf = [560, 520, 470, 540]
@@ -326,6 +330,49 @@ def test_captured_step_loop_and_decode_equal_eager():
             eng._check(eng.lib.vv_transformer_steps_into(eng.ctx, 3, d["N"], d["seq_len"].data_ptr(), graphs._host, x_e.data_ptr(), pre["cat_mel_text"].data_ptr(),
                                                          pre["cat_mel_text_drop"].data_ptr(), eng.rope[0].data_ptr(), eng.rope[1].data_ptr(), eng.rope[2].data_ptr(),
                                                          eng.rope[3].data_ptr(), 0, 1, graphs.ws.data_ptr(), 4096, torch.cuda.current_stream().cuda_stream))
+        eng.close()
+
+
+def test_two_lanes_equal_one_lane_bit_for_bit():
+    """The Euler steps of a batch as two half batches on two HIP streams (option "lanes" 2: lane 1 on a context-owned side stream
+    forked from and joined to the caller's stream inside the call) against the one-lane call: every item's state and PCM bit-identical,
+    in bf16 and fp32, on ragged batches of 2 / 3 / 5 items (cut at the item boundary closest to half of the rows), with the lengths
+    read back from the device and handed over on the host, split across two calls, and captured into ONE hipGraph (the side stream
+    joins the capture through the fork event).  Each lane is a complete sub-problem, so this is the batch-invariance property again."""
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    from vietvoice_tts_amd.runtime import HipSynth
+    spec = ModelSpec.small()
+    w = make_synthetic_weights(spec, seed=77)
+    cases = [([256 * 20, 256 * 31], [30, 47], [24, 40]), ([256 * 20, 256 * 12 + 100, 256 * 30], [30, 11, 47], [24, 9, 40]),
+             ([256 * 9, 256 * 40, 256 * 12, 256 * 25, 256 * 6], [8, 50, 20, 33, 5], [10, 44, 17, 30, 7])]
+    for dt in ("bf16", "fp32"):
+        eng = HipSynth(spec, w, acoustic_dtype=dt, nfe_step=6)
+        for la, lt, gf in cases:
+            batch = make_batch(spec, la, lt, gf, seed=len(la))
+            d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            lens = [int(v) for v in batch["seq_len"]]
+            pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"], seq_len_host=lens)
+            eng.set_option("lanes", 1)
+            x1 = d["noise"].clone()
+            eng.transformer_steps(x1, pre, 0, eng.n_steps)
+            pcm1, len1 = eng.decode(x1, pre, batch["t_gen_max"])
+            eng.set_option("lanes", 2)
+            x2 = d["noise"].clone()
+            eng.transformer_steps(x2, pre, 0, 2)                    # split across calls, host lengths
+            eng.transformer_steps(x2, pre, 2, eng.n_steps - 2)
+            pre_dev = dict(pre)
+            pre_dev.pop("seq_len_host", None)                       # lengths read back from the device
+            x3 = d["noise"].clone()
+            eng.transformer_steps(x3, pre_dev, 0, eng.n_steps)
+            torch.cuda.synchronize()
+            assert torch.equal(x2, x1) and torch.equal(x3, x1), (dt, len(la))
+            pcm2, len2 = eng.decode(x2, pre, batch["t_gen_max"])
+            assert torch.equal(pcm2, pcm1) and torch.equal(len2, len1)
+            graph = eng.capture_steps(len(la), d["N"], lens, batch["t_gen_max"])      # captured with two lanes
+            xg, pcmg, leng = graph(d["noise"], pre)
+            torch.cuda.synchronize()
+            assert torch.equal(xg, x1) and torch.equal(pcmg, pcm1) and torch.equal(leng, len1), (dt, len(la), "graph")
+        eng.set_option("lanes", 0)
         eng.close()
 
 

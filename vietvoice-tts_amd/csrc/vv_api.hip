@@ -53,6 +53,14 @@ struct vv_ctx {
                                         // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
+    int pp_min_tiles = -1;              // bf16 GEMMs of the path: -1 = the launcher's own choice between the persistent 256 x 256 kernel and the 128 x 128 one
+                                        // (vv_gemm.hip launch(): about one full round of 256-tiles, or the wide QKV shape); n >= 0 = the persistent
+                                        // kernel whenever M >= 4096, N % 256 == 0 and the shape has >= n 256-tiles (0 = the rule of rounds 1-3; lets a
+                                        // small model exercise the persistent kernel in the whole pipeline, tests/test_e2e_gpu.py).  Same bits either way.
+    int lanes = 0;                      // transformer steps as two half batches on two streams: 0 auto (bf16, >= VV_LANE_MIN_ROWS packed rows), 1 never,
+                                        // 2 whenever B >= 2
+    hipStream_t side_stream[1] = {};    // lane 1's stream (created on first use), forked from / joined to the caller's stream inside the call
+    hipEvent_t ev_fork = nullptr, ev_join[1] = {};
     float rope_theta = 0.f;             // > 0 (vv_set_rope_theta): the caller's rope tables are the standard ones of this base; the bf16 QKV epilogue then
                                         // computes cos / sin from the position (no table load), q leaves the GEMM without the softmax scale and the
                                         // attention kernel applies it (q_scale).  Overrides rope_q_attn.
@@ -160,6 +168,8 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
     g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q; g.rope_theta = rope_theta;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
+    if (c->pp_min_tiles >= 0 && dtype == VV_DTYPE_BF16 && N % 256 == 0)
+        g.tile = (M >= 4096 && (long long)((M + 255) / 256) * (N / 256) >= c->pp_min_tiles) ? 256 : 128;
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
     Prof p(c, VV_PROF_GEMM, fl, (double)M * K * esz + (double)N * K * esz + (double)M * N * osz * (mode == VV_EPI_GATE_RES ? 2 : 1), st);
@@ -213,6 +223,9 @@ void vv_destroy(vv_ctx* c) {
     if (c->fintab) hipFree(c->fintab);
     if (c->d_mult) hipFree(c->d_mult);
     if (c->x3_buf) hipFree(c->x3_buf);
+    for (auto q : c->side_stream) if (q) hipStreamDestroy(q);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    for (auto e : c->ev_join) if (e) hipEventDestroy(e);
     for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto e : c->pool) hipEventDestroy(e);
     delete c;
@@ -436,6 +449,35 @@ int vv_preprocess_h(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio,
 // --------------------------------------------------------------------------- transformer steps
 // ws_only != nullptr: only compute the workspace bytes the call would carve (nothing is launched; the data pointers may be null).
 // ext_ws != nullptr: carve from that caller-owned block instead of the context arena (what a captured hipGraph must point into).
+//
+// LANES (round 4): a batch of independent items may run as TWO half batches ("lanes") on two HIP streams at once -- lane 0 on the
+// caller's stream, lane 1 on a context-owned side stream forked from it and joined back before the call returns.  Every kernel of
+// the path is row- or sequence-local with one arithmetic whatever the launch size (tests/test_mixed256_gpu.py), so the lanes produce
+// exactly the bits of the whole batch; what changes is the schedule: the partial last round of one lane's persistent GEMM (1,600 tiles
+// on 256 CUs = 6.25 rounds at the headline shape), the tails of its other kernels and the launch gaps of small batches are filled by
+// the other lane's kernels instead of idling: -1.3 % of the step at B = 32, -3 % at 24, -5.5 % at 16 and 8, -9 % at 4
+// (profiles/r04/lanes_notes.md; three and four lanes, unequal cuts and CU-masked streams measured slower).  A lane is a complete
+// sub-problem: its own packed rows, row tables and buffers; the cut is the item boundary closest to half of the rows.
+namespace {
+constexpr size_t VV_LANE_MIN_ROWS = 2560;     // "lanes" auto: below ~2,500 packed rows the step is bound by the host's launch rate and a second stream of
+                                              // launches costs 1-2 % (profiles/r04/lanes_notes.md); above, two lanes win at every size measured
+struct Lane {
+    int B = 0, b0 = 0;
+    size_t Rc = 0, R = 0, n_tab = 0, tail_rows = 0;
+    double sum_sq = 0;
+    bool uniform = true, pending = false;
+    int tail_row0 = 0, tp_o = 0, tp_f = 0;
+    const int32_t* seq_len = nullptr;
+    float* x = nullptr;
+    const float *cat = nullptr, *cat_drop = nullptr;
+    hipStream_t st = nullptr;
+    char *xcat = nullptr, *h = nullptr, *h2 = nullptr, *h3 = nullptr, *qkv = nullptr, *att = nullptr, *ffm = nullptr;
+    float *xres = nullptr, *pred = nullptr, *csq = nullptr, *csk = nullptr, *csq_rows = nullptr, *csk_rows = nullptr, *h2_tail = nullptr, *h3_tail = nullptr;
+    int *kv_len = nullptr, *tab = nullptr;
+    const int *row_start = nullptr, *row_src = nullptr, *row_pos = nullptr, *qkv_pos = nullptr;
+};
+}  // namespace
+
 static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_len, const int32_t* seq_len_host, float* x, const float* cat,
                                   const float* cat_drop, const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k,
                                   const float* rope_sin_k, int step0, int n_steps, void* stream, void* ext_ws = nullptr,
@@ -463,151 +505,213 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         HIPCHK(c, hipMemcpyAsync(hlen.data(), seq_len, sizeof(int) * B, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
-    size_t Rc = 0;
-    double sum_sq = 0;
+    size_t Rc_all = 0;
     for (int b = 0; b < B; ++b) {
         if (hlen[b] < 1 || hlen[b] > N) return c->fail(-22, "vv_transformer_steps: seq_len[%d] = %d outside [1, %d]", b, hlen[b], N);
-        Rc += hlen[b]; sum_sq += (double)hlen[b] * hlen[b];
+        Rc_all += hlen[b];
     }
-    const size_t R = 2 * Rc;
-    if (R * 3 * (size_t)D * es >= ((size_t)1 << 31))
+    if (2 * Rc_all * 3 * (size_t)D * es >= ((size_t)1 << 31))
         return c->fail(-22, "vv_transformer_steps: %zu packed rows make a %zu-byte qkv buffer; kernels address it with 32-bit byte offsets "
-                            "(< 2 GiB) -- synthesise fewer units per call", R, R * 3 * (size_t)D * es);
-    // split-K tails of the two N = D gate-store GEMMs (out-proj K = D, FF2 K = FF): same row0 (it depends on M and N only)
-    int tail_row0 = 0, tp_o = 0, tp_f = 0;
-    if (c->split_k_tail && c->dt == VV_DTYPE_BF16) {
-        int r0o = 0, r0f = 0;
-        if (c->split_k_tail == 1) vvk_gemm_tail_plan((int)R, D, D, D, D, D, &r0o, &tp_o);          // (M, N, K, lda, ldw, ldc) of the launches below
-        vvk_gemm_tail_plan((int)R, D, FF, FF, FF, D, &r0f, &tp_f);
-        if (tp_o && tp_f && r0o != r0f) tp_o = tp_f = 0;   // cannot happen (row0 is a function of M, N and the CU count); refuse rather than mix
-        tail_row0 = tp_o ? r0o : r0f;
+                            "(< 2 GiB) -- synthesise fewer units per call", 2 * Rc_all, 2 * Rc_all * 3 * (size_t)D * es);
+    // lane plan: option "lanes" 1 = one lane, 2 = two whenever B >= 2, 0 (default) = two when both halves still fill the persistent
+    // GEMM for several rounds (>= VV_LANE_MIN_ROWS packed rows in all); the cut is the item boundary closest to half of the rows
+    int n_lanes = 1, cuts[3] = {0, B, B};
+    if (B >= 2 && (c->lanes == 2 || (c->lanes == 0 && c->dt == VV_DTYPE_BF16 && 2 * Rc_all >= (size_t)VV_LANE_MIN_ROWS))) {
+        size_t acc = 0, best = (size_t)-1;
+        for (int b = 1; b < B; ++b) {
+            acc += hlen[b - 1];
+            const size_t d = acc * 2 > Rc_all ? acc * 2 - Rc_all : Rc_all - acc * 2;
+            if (d < best) { best = d; cuts[1] = b; }
+        }
+        n_lanes = 2; cuts[2] = B;
     }
-    const size_t tail_rows = (tp_o || tp_f) ? R - tail_row0 : 0;
-    const size_t n_tab = 2 * (size_t)B + Rc + R;          // row_start[2B] | row_src[Rc] | row_pos[R]
+    Lane lanes[2];
     const int S = c->n_steps;
     Need nd;
-    nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
-    nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * n_tab);
-    nd.add(4ull * R * 64); nd.add(4ull * R * 64);
-    nd.add(4 * tail_rows * D * (tp_o > 1 ? tp_o : 0)); nd.add(4 * tail_rows * D * (tp_f > 1 ? tp_f : 0));
+    for (int li = 0; li < n_lanes; ++li) {
+        Lane& L = lanes[li];
+        L.b0 = cuts[li]; L.B = cuts[li + 1] - cuts[li];
+        for (int b = L.b0; b < L.b0 + L.B; ++b) { L.Rc += hlen[b]; L.sum_sq += (double)hlen[b] * hlen[b]; L.uniform = L.uniform && hlen[b] == N; }
+        L.R = 2 * L.Rc;
+        // split-K tails of the two N = D gate-store GEMMs (out-proj K = D, FF2 K = FF): same row0 (it depends on M and N only)
+        if (c->split_k_tail && c->dt == VV_DTYPE_BF16) {
+            int r0o = 0, r0f = 0;
+            if (c->split_k_tail == 1) vvk_gemm_tail_plan((int)L.R, D, D, D, D, D, &r0o, &L.tp_o);          // (M, N, K, lda, ldw, ldc) of the launches below
+            vvk_gemm_tail_plan((int)L.R, D, FF, FF, FF, D, &r0f, &L.tp_f);
+            if (L.tp_o && L.tp_f && r0o != r0f) L.tp_o = L.tp_f = 0;   // cannot happen (row0 is a function of M, N and the CU count); refuse rather than mix
+            L.tail_row0 = L.tp_o ? r0o : r0f;
+        }
+        L.tail_rows = (L.tp_o || L.tp_f) ? L.R - L.tail_row0 : 0;
+        L.n_tab = 2 * (size_t)L.B + L.Rc + L.R;          // row_start[2B] | row_src[Rc] | row_pos[R]
+        const size_t R = L.R;
+        nd.add(es * R * KP); nd.add(es * R * D); nd.add(es * R * D); nd.add(es * R * D); nd.add(4 * R * D); nd.add(es * R * 3 * D); nd.add(es * R * D);
+        nd.add(es * R * FF); nd.add(4 * R * MP); nd.add(4 * 2 * L.B); nd.add(4ull * N * 64); nd.add(4ull * N * 64); nd.add(4ull * L.n_tab);
+        nd.add(4ull * R * 64); nd.add(4ull * R * 64);
+        nd.add(4 * L.tail_rows * D * (L.tp_o > 1 ? L.tp_o : 0)); nd.add(4 * L.tail_rows * D * (L.tp_f > 1 ? L.tp_f : 0));
+    }
     if (ws_only) { *ws_only = (uint64_t)align_up(nd.b, 256); return 0; }
     if (ext_ws) { if (int r = use_ws(c, ext_ws, (size_t)ext_bytes, nd.b)) return r; }
     else if (int r = ensure_ws(c, nd.b)) return r;
-    char* xcat = carve<char>(c, es * R * KP);
-    char* h = carve<char>(c, es * R * D);
-    char* h2 = carve<char>(c, es * R * D);
-    char* h3 = carve<char>(c, es * R * D);
-    float* xres = carve<float>(c, R * D);
-    char* qkv = carve<char>(c, es * R * 3 * D);
-    char* att = carve<char>(c, es * R * D);
-    char* ffm = carve<char>(c, es * R * FF);
-    float* pred = carve<float>(c, R * MP);
-    int* kv_len = carve<int>(c, 2 * B);
-    float* csq = carve<float>(c, (size_t)N * 64);
-    float* csk = carve<float>(c, (size_t)N * 64);
-    int* tab = carve<int>(c, n_tab);
-    float* csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
-    float* csk_rows = carve<float>(c, R * 64);
-    float* h2_tail = carve<float>(c, tail_rows * D * (tp_o > 1 ? tp_o : 0));     // fp32 [parts][tail_rows][D] K parts of the tail rows' deltas
-    float* h3_tail = carve<float>(c, tail_rows * D * (tp_f > 1 ? tp_f : 0));
-    const int* row_start = tab; const int* row_src = tab + 2 * B; const int* row_pos = row_src + Rc;
-    KCHK(c, vvk_row_tables(seq_len, B, N, (int)Rc, tab, tab + 2 * B, tab + 2 * B + Rc, st, &m__));
-    const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? csq_rows : csq, c->rope_rows ? csk_rows : csk};
-    KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, csq, N, st, &m__));
-    KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, csk, N, st, &m__));
-    if (c->rope_rows) {
-        KCHK(c, vvk_rope_rows(csq, row_pos, csq_rows, (int)R, st, &m__));
-        KCHK(c, vvk_rope_rows(csk, row_pos, csk_rows, (int)R, st, &m__));
+    for (int li = 1; li < n_lanes; ++li)
+        if (!c->side_stream[li - 1]) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[li - 1], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[li - 1], hipEventDisableTiming));
+        }
+    if (n_lanes > 1 && !c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int li = 0; li < n_lanes; ++li) {
+        Lane& L = lanes[li];
+        const size_t R = L.R;
+        L.seq_len = seq_len + L.b0; L.x = x + (size_t)L.b0 * N * M; L.cat = cat + (size_t)L.b0 * N * CD; L.cat_drop = cat_drop + (size_t)L.b0 * N * CD;
+        L.st = li == 0 ? st : c->side_stream[li - 1];
+        L.xcat = carve<char>(c, es * R * KP);
+        L.h = carve<char>(c, es * R * D);
+        L.h2 = carve<char>(c, es * R * D);
+        L.h3 = carve<char>(c, es * R * D);
+        L.xres = carve<float>(c, R * D);
+        L.qkv = carve<char>(c, es * R * 3 * D);
+        L.att = carve<char>(c, es * R * D);
+        L.ffm = carve<char>(c, es * R * FF);
+        L.pred = carve<float>(c, R * MP);
+        L.kv_len = carve<int>(c, 2 * L.B);
+        L.csq = carve<float>(c, (size_t)N * 64);
+        L.csk = carve<float>(c, (size_t)N * 64);
+        L.tab = carve<int>(c, L.n_tab);
+        L.csq_rows = carve<float>(c, R * 64);          // compact rope tables gathered per packed row, once per call
+        L.csk_rows = carve<float>(c, R * 64);
+        L.h2_tail = carve<float>(c, L.tail_rows * D * (L.tp_o > 1 ? L.tp_o : 0));     // fp32 [parts][tail_rows][D] K parts of the tail rows' deltas
+        L.h3_tail = carve<float>(c, L.tail_rows * D * (L.tp_f > 1 ? L.tp_f : 0));
+        L.row_start = L.tab; L.row_src = L.tab + 2 * L.B; L.row_pos = L.row_src + L.Rc;
+        L.qkv_pos = L.uniform ? nullptr : L.row_pos;   // every sequence N rows: position = packed row mod N, no table lookup
     }
-    bool uniform = true;                                   // every sequence N rows: position = packed row mod N, no table lookup
-    for (int b = 0; b < B; ++b) uniform = uniform && hlen[b] == N;
-    const int* qkv_pos = uniform ? nullptr : row_pos;
     // bf16: the query side of the rope moves from the QKV GEMM's epilogue into the attention kernel's Q load (option "rope_q_attn",
     // default on; profiles/r04/attention_notes.md); the fp32 (numerics) path keeps all of it in the GEMM
     const float rope_theta = c->dt == VV_DTYPE_BF16 ? c->rope_theta : 0.f;        // computed rope: both q and k in the GEMM epilogue, scale in attention
     const int q_rope_attn = (c->rope_q_attn && c->dt == VV_DTYPE_BF16 && !(rope_theta > 0.f)) ? 1 : 0;
 
-    KCHK(c, vvk_dup_len(seq_len, kv_len, B, st, &m__));
-    {
-        Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * R * (M + CD) / 2 + (double)es * R * KP, st);
-        KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, (int)Rc, M, CD, 0, row_src, st, &m__));
-    }
-    for (int s = step0; s < step0 + n_steps; ++s) {
+    auto setup = [&](Lane& L) -> int {
+        hipStream_t st = L.st;
+        KCHK(c, vvk_row_tables(L.seq_len, L.B, N, (int)L.Rc, L.tab, L.tab + 2 * L.B, L.tab + 2 * L.B + L.Rc, st, &m__));
+        KCHK(c, vvk_rope_compact(rope_cos_q, rope_sin_q, L.csq, N, st, &m__));
+        KCHK(c, vvk_rope_compact(rope_cos_k, rope_sin_k, L.csk, N, st, &m__));
+        if (c->rope_rows) {
+            KCHK(c, vvk_rope_rows(L.csq, L.row_pos, L.csq_rows, (int)L.R, st, &m__));
+            KCHK(c, vvk_rope_rows(L.csk, L.row_pos, L.csk_rows, (int)L.R, st, &m__));
+        }
+        KCHK(c, vvk_dup_len(L.seq_len, L.kv_len, L.B, st, &m__));
+        Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * L.R * (M + CD) / 2 + (double)es * L.R * KP, st);
+        KCHK(c, vvk_pack_cat(c->dt, L.x, L.cat, L.cat_drop, L.xcat, KP, (int)L.Rc, M, CD, 0, L.row_src, st, &m__));
+        return 0;
+    };
+    // input embedding of step s: proj, then conv position embedding (two grouped convs + Mish) + residual
+    auto step_head = [&](Lane& L, int s) -> int {
+        hipStream_t st = L.st;
+        const size_t R = L.R, Rc = L.Rc;
         if (s != step0) {
             Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * Rc * M + 2.0 * es * Rc * M, st);
-            KCHK(c, vvk_pack_cat(c->dt, x, cat, cat_drop, xcat, KP, (int)Rc, M, CD, 1, row_src, st, &m__));
+            KCHK(c, vvk_pack_cat(c->dt, L.x, L.cat, L.cat_drop, L.xcat, KP, (int)Rc, M, CD, 1, L.row_src, st, &m__));
         }
-        // input embedding: proj, then conv position embedding (two grouped convs + Mish) + residual
-        if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_NONE_, xcat, KP, "input.proj.weight", KP, "input.proj.bias", h, D, (int)R, D, KP, st,
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_NONE_, L.xcat, KP, "input.proj.weight", KP, "input.proj.bias", L.h, D, (int)R, D, KP, st,
                          nullptr, 0, nullptr, 0, 0, 2.0 * R * D * (M + CD))) return r;
         for (int j = 1; j <= 2; ++j) {
             vv_posconv_args a{};
             a.dtype = c->dt; a.out_dtype = (j == 1) ? c->dt : VV_DTYPE_F32;
-            a.in = (j == 1) ? h : h2; a.ld_in = D;
+            a.in = (j == 1) ? L.h : L.h2; a.ld_in = D;
             const std::string wn = "input.pos_conv" + std::to_string(j) + ".weight", bn = "input.pos_conv" + std::to_string(j) + ".bias";
             a.W = c->W(wn); a.bias = c->Wf(bn);
-            a.out = (j == 1) ? (void*)h2 : (void*)xres; a.ld_out = D;
-            a.resid = (j == 2) ? h : nullptr; a.ld_resid = D;
-            a.n_seq = 2 * B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * B; a.seq_len = kv_len; a.row_start = row_start;
+            a.out = (j == 1) ? (void*)L.h2 : (void*)L.xres; a.ld_out = D;
+            a.resid = (j == 2) ? L.h : nullptr; a.ld_resid = D;
+            a.n_seq = 2 * L.B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * L.B; a.seq_len = L.kv_len; a.row_start = L.row_start;
             Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
             KCHK(c, vvk_posconv(&a, st, &m__));
         }
-        // Residual stream protocol: a branch GEMM writes delta = gate * (out + bias) (operand dtype) and a LayerNorm kernel adds
-        // it while it streams x anyway (no read-modify-write in a GEMM epilogue).  x is REWRITTEN ONCE PER BLOCK: the norm
-        // before the MLP normalises x + d_attn without storing it (keep_x), the next block's first norm stores
-        // (x + d_attn) + d_mlp -- the same additions in the same order, a third fewer bytes written by the norm kernels.
-        bool pending = false;
-        for (int l = 0; l < g.depth; ++l) {
-            const float* mod = c->modtab + ((size_t)l * S + s) * 6 * D;
-            const std::string qkvw = blk(l, ".attn.qkv.weight"), qkvb = blk(l, ".attn.qkv.bias"), ow = blk(l, ".attn.out.weight"),
-                              ob = blk(l, ".attn.out.bias"), f1w = blk(l, ".ff1.weight"), f1b = blk(l, ".ff1.bias"),
-                              f2w = blk(l, ".ff2.weight"), f2b = blk(l, ".ff2.bias");
-            vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
-            a.delta_dtype = c->dt; a.ld_delta = D;
-            a.tail_row0 = tail_row0; a.delta_tail = h2_tail; a.delta2_tail = h3_tail;
-            a.delta_tail_parts = pending ? tp_o : 0; a.delta2_tail_parts = pending ? tp_f : 0;
-            a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
-            a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 0;
-            { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, h, D, qkvw.c_str(), D, qkvb.c_str(), qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, qkv_pos, c->rope_rows,
-                             nullptr, 0, 0, q_rope_attn, rope_theta)) return r;
-            {
-                vv_attn_args t{}; t.dtype = c->dt; t.qkv = qkv; t.ld_qkv = 3 * D; t.out = att; t.ld_out = D; t.n_seq = 2 * B; t.seq_n = N;
-                t.heads = g.heads; t.dim = D; t.kv_len = kv_len; t.row_start = row_start; t.total_rows = (int)R;
-                t.rope_cs_q = q_rope_attn ? csq : nullptr;
-                t.q_scale = rope_theta > 0.f ? 1.0f / sqrtf((float)g.head_dim) : 0.f;
-                Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * sum_sq * 64, (double)es * R * 4 * D, st);
-                KCHK(c, vvk_attention(&t, st, &m__));
-            }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, att, D, ow.c_str(), D, ob.c_str(), h2, D, (int)R, D, D, st, mod + 2 * D,
-                             0, nullptr, 0, 0, -1, nullptr, 0, tp_o ? h2_tail : nullptr, tp_o ? tail_row0 : 0, tp_o)) return r;
-            a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
-            a.delta = h2; a.delta2 = nullptr; a.keep_x = 1; a.delta_tail_parts = tp_o; a.delta2_tail_parts = 0;
-            { Prof p(c, VV_PROF_NORM, 0, (4.0 + 2.0 * es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, h, D, f1w.c_str(), D, f1b.c_str(), ffm, FF, (int)R, FF, D, st)) return r;
-            if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, ffm, FF, f2w.c_str(), FF, f2b.c_str(), h3, D, (int)R, D, FF, st, mod + 5 * D,
-                             0, nullptr, 0, 0, -1, nullptr, 0, tp_f ? h3_tail : nullptr, tp_f ? tail_row0 : 0, tp_f)) return r;
-            pending = true;
+        L.pending = false;
+        return 0;
+    };
+    // Residual stream protocol: a branch GEMM writes delta = gate * (out + bias) (operand dtype) and a LayerNorm kernel adds
+    // it while it streams x anyway (no read-modify-write in a GEMM epilogue).  x is REWRITTEN ONCE PER BLOCK: the norm
+    // before the MLP normalises x + d_attn without storing it (keep_x), the next block's first norm stores
+    // (x + d_attn) + d_mlp -- the same additions in the same order, a third fewer bytes written by the norm kernels.
+    auto block = [&](Lane& L, int s, int l) -> int {
+        hipStream_t st = L.st;
+        const size_t R = L.R;
+        const bool pending = L.pending;
+        const float* rope[6] = {rope_cos_q, rope_sin_q, rope_cos_k, rope_sin_k, c->rope_rows ? L.csq_rows : L.csq, c->rope_rows ? L.csk_rows : L.csk};
+        const float* mod = c->modtab + ((size_t)l * S + s) * 6 * D;
+        const std::string qkvw = blk(l, ".attn.qkv.weight"), qkvb = blk(l, ".attn.qkv.bias"), ow = blk(l, ".attn.out.weight"),
+                          ob = blk(l, ".attn.out.bias"), f1w = blk(l, ".ff1.weight"), f1b = blk(l, ".ff1.bias"),
+                          f2w = blk(l, ".ff2.weight"), f2b = blk(l, ".ff2.bias");
+        vv_ln_args a{}; a.out_dtype = c->dt; a.x = L.xres; a.ldx = D; a.y = L.h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
+        a.delta_dtype = c->dt; a.ld_delta = D;
+        a.tail_row0 = L.tail_row0; a.delta_tail = L.h2_tail; a.delta2_tail = L.h3_tail;
+        a.delta_tail_parts = pending ? L.tp_o : 0; a.delta2_tail_parts = pending ? L.tp_f : 0;
+        a.w = mod + D; a.b = mod;                       // scale_msa, shift_msa
+        a.delta = pending ? L.h2 : nullptr; a.delta2 = pending ? L.h3 : nullptr; a.keep_x = 0;
+        { Prof p(c, VV_PROF_NORM, 0, (4.0 + es) * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 0), st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, L.h, D, qkvw.c_str(), D, qkvb.c_str(), L.qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, L.qkv_pos, c->rope_rows,
+                         nullptr, 0, 0, q_rope_attn, rope_theta)) return r;
+        {
+            vv_attn_args t{}; t.dtype = c->dt; t.qkv = L.qkv; t.ld_qkv = 3 * D; t.out = L.att; t.ld_out = D; t.n_seq = 2 * L.B; t.seq_n = N;
+            t.heads = g.heads; t.dim = D; t.kv_len = L.kv_len; t.row_start = L.row_start; t.total_rows = (int)R;
+            t.rope_cs_q = q_rope_attn ? L.csq : nullptr;
+            t.q_scale = rope_theta > 0.f ? 1.0f / sqrtf((float)g.head_dim) : 0.f;
+            Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * L.sum_sq * 64, (double)es * R * 4 * D, st);
+            KCHK(c, vvk_attention(&t, st, &m__));
         }
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, L.att, D, ow.c_str(), D, ob.c_str(), L.h2, D, (int)R, D, D, st, mod + 2 * D,
+                         0, nullptr, 0, 0, -1, nullptr, 0, L.tp_o ? L.h2_tail : nullptr, L.tp_o ? L.tail_row0 : 0, L.tp_o)) return r;
+        a.w = mod + 4 * D; a.b = mod + 3 * D;           // scale_mlp, shift_mlp
+        a.delta = L.h2; a.delta2 = nullptr; a.keep_x = 1; a.delta_tail_parts = L.tp_o; a.delta2_tail_parts = 0;
+        { Prof p(c, VV_PROF_NORM, 0, (4.0 + 2.0 * es) * R * D, st); KCHK(c, vvk_ln_mod(&a, st, &m__)); }
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_GELU_TANH_, L.h, D, f1w.c_str(), D, f1b.c_str(), L.ffm, FF, (int)R, FF, D, st)) return r;
+        if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, L.ffm, FF, f2w.c_str(), FF, f2b.c_str(), L.h3, D, (int)R, D, FF, st, mod + 5 * D,
+                         0, nullptr, 0, 0, -1, nullptr, 0, L.tp_f ? L.h3_tail : nullptr, L.tp_f ? L.tail_row0 : 0, L.tp_f)) return r;
+        L.pending = true;
+        return 0;
+    };
+    auto step_tail = [&](Lane& L, int s) -> int {
+        hipStream_t st = L.st;
+        const size_t R = L.R, Rc = L.Rc;
+        const bool pending = L.pending;
         {
             const float* fm = c->fintab + (size_t)s * 2 * D;
-            vv_ln_args a{}; a.out_dtype = c->dt; a.x = xres; a.ldx = D; a.y = h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
+            vv_ln_args a{}; a.out_dtype = c->dt; a.x = L.xres; a.ldx = D; a.y = L.h; a.ldy = D; a.R = (int)R; a.D = D; a.add_one = 1; a.eps = 1e-6f;
             a.w = fm; a.b = fm + D;                          // scale, shift
-            a.delta = pending ? h2 : nullptr; a.delta2 = pending ? h3 : nullptr; a.keep_x = 1;     // x is re-initialised by the next step
+            a.delta = pending ? L.h2 : nullptr; a.delta2 = pending ? L.h3 : nullptr; a.keep_x = 1;     // x is re-initialised by the next step
             a.delta_dtype = c->dt; a.ld_delta = D;
-            a.tail_row0 = tail_row0; a.delta_tail = h2_tail; a.delta2_tail = h3_tail;
-            a.delta_tail_parts = pending ? tp_o : 0; a.delta2_tail_parts = pending ? tp_f : 0;
+            a.tail_row0 = L.tail_row0; a.delta_tail = L.h2_tail; a.delta2_tail = L.h3_tail;
+            a.delta_tail_parts = pending ? L.tp_o : 0; a.delta2_tail_parts = pending ? L.tp_f : 0;
             Prof p(c, VV_PROF_NORM, 0, es * R * D + (pending ? (4.0 + 2.0 * es) * R * D : 4.0 * R * D), st);
             KCHK(c, vvk_ln_mod(&a, st, &m__));
         }
-        if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, h, D, "final.proj.weight", D, "final.proj.bias", pred, MP, (int)R, MP, D, st,
+        if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, L.h, D, "final.proj.weight", D, "final.proj.bias", L.pred, MP, (int)R, MP, D, st,
                          nullptr, M, nullptr, 0, 0, 2.0 * R * D * M)) return r;
         {
             Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * Rc * M, st);
-            KCHK(c, vvk_cfg_euler(x, pred, MP, (int)Rc, M, g.cfg_strength, c->dt_host[s], row_src, st, &m__));
+            KCHK(c, vvk_cfg_euler(L.x, L.pred, MP, (int)Rc, M, g.cfg_strength, c->dt_host[s], L.row_src, st, &m__));
         }
+        return 0;
+    };
+
+    // Launch order: the lanes alternate block by block, so both streams always hold work and neither lane's enqueue waits for the
+    // other's queue to drain; the device orders each stream by itself.  Lane 1 forks from the caller's stream (what the caller
+    // enqueued before this call is visible to it) and joins back at the end (what the caller enqueues next sees both lanes).
+    if (n_lanes > 1) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        for (int li = 1; li < n_lanes; ++li) HIPCHK(c, hipStreamWaitEvent(c->side_stream[li - 1], c->ev_fork, 0));
     }
-    return 0;
+    int rc = 0;
+    for (int li = 0; li < n_lanes && !rc; ++li) rc = setup(lanes[li]);
+    for (int s = step0; s < step0 + n_steps && !rc; ++s) {
+        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_head(lanes[li], s);
+        for (int l = 0; l < g.depth && !rc; ++l)
+            for (int li = 0; li < n_lanes && !rc; ++li) rc = block(lanes[li], s, l);
+        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_tail(lanes[li], s);
+    }
+    for (int li = 1; li < n_lanes; ++li) {                 // always join, also after a failed launch: no side stream may outlive the call
+        hipEventRecord(c->ev_join[li - 1], c->side_stream[li - 1]);
+        hipStreamWaitEvent(st, c->ev_join[li - 1], 0);
+    }
+    return rc;
 }
 
 int vv_transformer_steps(vv_ctx* c, int B, int N, const int32_t* seq_len, float* x, const float* cat, const float* cat_drop,
@@ -787,6 +891,14 @@ int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!strcmp(name, "split_k_tail")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: split_k_tail takes 0 (off), 1 (out-projection and FF2) or 2 (FF2 only)");
         c->split_k_tail = value; return 0;
+    }
+    if (!strcmp(name, "pp_min_tiles")) {
+        if (value < -1) return c->fail(-22, "vv_set_option: pp_min_tiles takes -1 (the launcher's rule) or a 256-tile count >= 0");
+        c->pp_min_tiles = value; return 0;
+    }
+    if (!strcmp(name, "lanes")) {
+        if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: lanes takes 0 (auto), 1 (one lane) or 2 (two lanes whenever the batch has two items)");
+        c->lanes = value; return 0;
     }
     if (!strcmp(name, "fuse_mrf")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: fuse_mrf takes 0 (off), 1 (on) or 2 (auto)");

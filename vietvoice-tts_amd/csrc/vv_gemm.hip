@@ -958,6 +958,9 @@ hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, in
     auto kern = gemm_pp_kernel<MODE, To>;
     int n_cu = 256;
     if (hipError_t he = setup.ensure((const void*)kern, LDS, &n_cu); he != hipSuccess) return he;
+#ifdef VV_GEMM_EXP
+    if (const char* v = getenv("VV_GEMM_GRID")) { const int gc = atoi(v) / 8 * 8; if (gc >= 8 && gc <= n_cu) n_cu = gc; }   // CU-masked stream probe
+#endif
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     const int total = m_tiles * n_tiles;
     const int grid = std::min(n_cu, (total + 7) / 8 * 8);      // one persistent workgroup per CU, a multiple of the 8 XCD labels
@@ -982,8 +985,13 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
 template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                   hipStream_t st, int force_tile) {
-    const bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
+    bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
     if constexpr (sizeof(T) == 2) {
+        // auto: below one full round of 256 x 256 tiles the persistent kernel leaves CUs idle for its whole length and the 128 x 128
+        // kernel (four times the tiles, two workgroups per CU) is faster -- out-projection / FF2 up to M = 12,800, FF1 up to 6,400 --
+        // except for the wide QKV shape, where the persistent kernel wins from M = 4,096 on (profiles/r04/gemm_tile_by_m.txt).  Both
+        // kernels produce the same bits (one arithmetic, tests/test_kernels_gpu.py), so the choice is speed only.
+        if (force_tile == 0 && big && N < 3072 && (long long)((M + 255) / 256) * (N / 256) < device_cus()) big = false;
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
         if (big && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
