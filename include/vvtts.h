@@ -162,8 +162,9 @@ VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
  * "lanes": vv_transformer_steps* runs a batch of >= 2 items as TWO half batches on two HIP streams -- lane 0 on the caller's stream,
  * lane 1 on a context-owned stream forked from it at the start of the call and joined to it before the call returns (so the call
  * keeps its stream semantics, and can be captured into a hipGraph) -- so that one lane's kernel tails and launch gaps are filled by
- * the other's kernels.  0 (default) = for the bf16 model from 2,560 packed rows (2 x sum of the lengths) on, 1 = never, 2 = whenever
- * the batch has two items.  Results are bit-identical: every item's arithmetic is independent of its batch.
+ * the other's kernels.  A single item runs its two CFG branches (conditional / unconditional rows) as the lanes, forked and joined once
+ * per Euler step.  0 (default) = for the bf16 model from 2,560 packed rows (2 x sum of the lengths) on, 1 = never, 2 = always.
+ * Results are bit-identical: every row's arithmetic is independent of what shares its launch.
  * "pp_min_tiles": -1 (default) = vv_gemm's own choice between its persistent 256 x 256 kernel and the 128 x 128 one; n >= 0 = the
  * persistent kernel for every bf16 GEMM of the path with M >= 4096, N % 256 == 0 and >= n 256-tiles.  Same bits either way. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);

@@ -336,14 +336,16 @@ def test_captured_step_loop_and_decode_equal_eager():
 def test_two_lanes_equal_one_lane_bit_for_bit():
     """The Euler steps of a batch as two half batches on two HIP streams (option "lanes" 2: lane 1 on a context-owned side stream
     forked from and joined to the caller's stream inside the call) against the one-lane call: every item's state and PCM bit-identical,
-    in bf16 and fp32, on ragged batches of 2 / 3 / 5 items (cut at the item boundary closest to half of the rows), with the lengths
+    in bf16 and fp32, on a single item (then the two CFG branches are the lanes: conditional and unconditional rows of the same packed
+    buffers, fork / join once per step) and on ragged batches of 2 / 3 / 5 items (cut at the item boundary closest to half of the rows), with the lengths
     read back from the device and handed over on the host, split across two calls, and captured into ONE hipGraph (the side stream
     joins the capture through the fork event).  Each lane is a complete sub-problem, so this is the batch-invariance property again."""
     from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
     from vietvoice_tts_amd.runtime import HipSynth
     spec = ModelSpec.small()
     w = make_synthetic_weights(spec, seed=77)
-    cases = [([256 * 20, 256 * 31], [30, 47], [24, 40]), ([256 * 20, 256 * 12 + 100, 256 * 30], [30, 11, 47], [24, 9, 40]),
+    cases = [([256 * 26], [41], [33]),                 # ONE item: the lanes are its two CFG branches, forked and joined once per step
+             ([256 * 20, 256 * 31], [30, 47], [24, 40]), ([256 * 20, 256 * 12 + 100, 256 * 30], [30, 11, 47], [24, 9, 40]),
              ([256 * 9, 256 * 40, 256 * 12, 256 * 25, 256 * 6], [8, 50, 20, 33, 5], [10, 44, 17, 30, 7])]
     for dt in ("bf16", "fp32"):
         eng = HipSynth(spec, w, acoustic_dtype=dt, nfe_step=6)

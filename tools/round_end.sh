@@ -16,8 +16,18 @@ python bench.py --batch 1 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_b
 python bench.py --batch 1 --dtype fp32 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_b1_fp32.json 2>/dev/null; echo "b1 fp32 rc=$?"
 python bench.py --workload serve > $OUT/bench_serve_c16.json 2>/dev/null; echo "serve rc=$?"
 cd /tmp && export TMPDIR=/tmp
+# kernel-trace summary twice: (1) every pass on ONE lane -- each kernel with the chip to itself, the durations bench.py's roofline figures
+# (its one-lane HIP-event pass) must agree with; (2) the default command: warm-up and timed steps on two lanes (half-batch kernels that
+# overlap), the class pass on one
+export VV_BENCH_OPTIONS=lanes=1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_kt -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/prof_kt.err
-echo "kernel-trace rc=$?"
+rc=$?; echo "kernel-trace (one lane) rc=$rc"; [ $rc -eq 0 ] || exit 1
+unset VV_BENCH_OPTIONS
 DB=$(find $OUT/prof_kt -name "*.db" | head -1)
 [ -n "$DB" ] && python3 $ROOT/tools/rocpd_kernel_stats.py $DB $OUT/bench_kernel_stats.csv
 rm -rf $OUT/prof_kt
+rocprofv3 --kernel-trace --stats -d $OUT/prof_kt2 -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof_two_lanes.json 2> $OUT/prof_kt2.err
+echo "kernel-trace (default: two lanes) rc=$?"
+DB=$(find $OUT/prof_kt2 -name "*.db" | head -1)
+[ -n "$DB" ] && python3 $ROOT/tools/rocpd_kernel_stats.py $DB $OUT/bench_kernel_stats_two_lanes.csv && python3 $ROOT/tools/lanes_timeline.py $DB > $OUT/lanes_timeline_under_rocprof.txt
+rm -rf $OUT/prof_kt2

@@ -463,8 +463,9 @@ constexpr size_t VV_LANE_MIN_ROWS = 2560;     // "lanes" auto: below ~2,500 pack
                                               // launches costs 1-2 % (profiles/r04/lanes_notes.md); above, two lanes win at every size measured
 struct Lane {
     int B = 0, b0 = 0;
+    int n_seq = 0;                     // sequences the block kernels of this lane (or branch view) run on: 2 B, or B for one CFG branch
     size_t Rc = 0, R = 0, n_tab = 0, tail_rows = 0;
-    double sum_sq = 0;
+    double sum_sq = 0;                 // sum of len^2 over those sequences (attention flops)
     bool uniform = true, pending = false;
     int tail_row0 = 0, tp_o = 0, tp_f = 0;
     const int32_t* seq_len = nullptr;
@@ -525,14 +526,19 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         }
         n_lanes = 2; cuts[2] = B;
     }
+    // One problem only (a single item, or a batch under the row threshold with "lanes" 2): its two CFG BRANCHES are the lanes -- the
+    // conditional rows [0, Rc) and the unconditional rows [Rc, 2 Rc) of the same packed buffers are independent from the conditioning
+    // pack at the top of a step to the CFG combine at its end, so the side stream is forked and joined once per step around them.
+    const bool branch_lanes = n_lanes == 1 && !(c->split_k_tail && c->dt == VV_DTYPE_BF16) &&
+                              (c->lanes == 2 || (c->lanes == 0 && c->dt == VV_DTYPE_BF16 && 2 * Rc_all >= (size_t)VV_LANE_MIN_ROWS));
     Lane lanes[2];
     const int S = c->n_steps;
     Need nd;
     for (int li = 0; li < n_lanes; ++li) {
         Lane& L = lanes[li];
         L.b0 = cuts[li]; L.B = cuts[li + 1] - cuts[li];
-        for (int b = L.b0; b < L.b0 + L.B; ++b) { L.Rc += hlen[b]; L.sum_sq += (double)hlen[b] * hlen[b]; L.uniform = L.uniform && hlen[b] == N; }
-        L.R = 2 * L.Rc;
+        for (int b = L.b0; b < L.b0 + L.B; ++b) { L.Rc += hlen[b]; L.sum_sq += 2.0 * hlen[b] * hlen[b]; L.uniform = L.uniform && hlen[b] == N; }
+        L.R = 2 * L.Rc; L.n_seq = 2 * L.B;
         // split-K tails of the two N = D gate-store GEMMs (out-proj K = D, FF2 K = FF): same row0 (it depends on M and N only)
         if (c->split_k_tail && c->dt == VV_DTYPE_BF16) {
             int r0o = 0, r0f = 0;
@@ -552,12 +558,12 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     if (ws_only) { *ws_only = (uint64_t)align_up(nd.b, 256); return 0; }
     if (ext_ws) { if (int r = use_ws(c, ext_ws, (size_t)ext_bytes, nd.b)) return r; }
     else if (int r = ensure_ws(c, nd.b)) return r;
-    for (int li = 1; li < n_lanes; ++li)
+    for (int li = 1; li < (branch_lanes ? 2 : n_lanes); ++li)
         if (!c->side_stream[li - 1]) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[li - 1], hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[li - 1], hipEventDisableTiming));
         }
-    if (n_lanes > 1 && !c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if ((n_lanes > 1 || branch_lanes) && !c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int li = 0; li < n_lanes; ++li) {
         Lane& L = lanes[li];
         const size_t R = L.R;
@@ -603,13 +609,19 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         return 0;
     };
     // input embedding of step s: proj, then conv position embedding (two grouped convs + Mish) + residual
-    auto step_head = [&](Lane& L, int s) -> int {
+    auto step_pack = [&](Lane& L, int s) -> int {
         hipStream_t st = L.st;
-        const size_t R = L.R, Rc = L.Rc;
+        const size_t Rc = L.Rc;
         if (s != step0) {
             Prof p(c, VV_PROF_ELEMWISE, 0, 4.0 * Rc * M + 2.0 * es * Rc * M, st);
             KCHK(c, vvk_pack_cat(c->dt, L.x, L.cat, L.cat_drop, L.xcat, KP, (int)Rc, M, CD, 1, L.row_src, st, &m__));
         }
+        return 0;
+    };
+    auto step_head = [&](Lane& L, int s) -> int {
+        (void)s;
+        hipStream_t st = L.st;
+        const size_t R = L.R;
         if (int r = gemm(c, c->dt, c->dt, VV_EPI_STORE, VV_ACT_NONE_, L.xcat, KP, "input.proj.weight", KP, "input.proj.bias", L.h, D, (int)R, D, KP, st,
                          nullptr, 0, nullptr, 0, 0, 2.0 * R * D * (M + CD))) return r;
         for (int j = 1; j <= 2; ++j) {
@@ -620,7 +632,7 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
             a.W = c->W(wn); a.bias = c->Wf(bn);
             a.out = (j == 1) ? (void*)L.h2 : (void*)L.xres; a.ld_out = D;
             a.resid = (j == 2) ? L.h : nullptr; a.ld_resid = D;
-            a.n_seq = 2 * L.B; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = 2 * L.B; a.seq_len = L.kv_len; a.row_start = L.row_start;
+            a.n_seq = L.n_seq; a.seq_n = N; a.groups = g.pos_conv_groups; a.KW = g.pos_conv_k; a.B = L.n_seq; a.seq_len = L.kv_len; a.row_start = L.row_start;
             Prof p(c, VV_PROF_POSCONV, 2.0 * R * D * 64 * g.pos_conv_k, (double)es * R * D * 2 + (j == 2 ? 4.0 * R * D : 0), st);
             KCHK(c, vvk_posconv(&a, st, &m__));
         }
@@ -650,11 +662,11 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         if (int r = gemm(c, c->dt, c->dt, VV_EPI_QKV_ROPE, VV_ACT_NONE_, L.h, D, qkvw.c_str(), D, qkvb.c_str(), L.qkv, 3 * D, (int)R, 3 * D, D, st, nullptr, 0, rope, N, D, -1, L.qkv_pos, c->rope_rows,
                          nullptr, 0, 0, q_rope_attn, rope_theta)) return r;
         {
-            vv_attn_args t{}; t.dtype = c->dt; t.qkv = L.qkv; t.ld_qkv = 3 * D; t.out = L.att; t.ld_out = D; t.n_seq = 2 * L.B; t.seq_n = N;
+            vv_attn_args t{}; t.dtype = c->dt; t.qkv = L.qkv; t.ld_qkv = 3 * D; t.out = L.att; t.ld_out = D; t.n_seq = L.n_seq; t.seq_n = N;
             t.heads = g.heads; t.dim = D; t.kv_len = L.kv_len; t.row_start = L.row_start; t.total_rows = (int)R;
             t.rope_cs_q = q_rope_attn ? L.csq : nullptr;
             t.q_scale = rope_theta > 0.f ? 1.0f / sqrtf((float)g.head_dim) : 0.f;
-            Prof p(c, VV_PROF_ATTN, 4.0 * 2 * g.heads * L.sum_sq * 64, (double)es * R * 4 * D, st);
+            Prof p(c, VV_PROF_ATTN, 4.0 * g.heads * L.sum_sq * 64, (double)es * R * 4 * D, st);
             KCHK(c, vvk_attention(&t, st, &m__));
         }
         if (int r = gemm(c, c->dt, c->dt, VV_EPI_GATE_STORE, VV_ACT_NONE_, L.att, D, ow.c_str(), D, ob.c_str(), L.h2, D, (int)R, D, D, st, mod + 2 * D,
@@ -670,7 +682,7 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
     };
     auto step_tail = [&](Lane& L, int s) -> int {
         hipStream_t st = L.st;
-        const size_t R = L.R, Rc = L.Rc;
+        const size_t R = L.R;
         const bool pending = L.pending;
         {
             const float* fm = c->fintab + (size_t)s * 2 * D;
@@ -685,32 +697,63 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         }
         if (int r = gemm(c, c->dt, VV_DTYPE_F32, VV_EPI_STORE, VV_ACT_NONE_, L.h, D, "final.proj.weight", D, "final.proj.bias", L.pred, MP, (int)R, MP, D, st,
                          nullptr, M, nullptr, 0, 0, 2.0 * R * D * M)) return r;
-        {
-            Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * Rc * M, st);
-            KCHK(c, vvk_cfg_euler(L.x, L.pred, MP, (int)Rc, M, g.cfg_strength, c->dt_host[s], L.row_src, st, &m__));
-        }
+        return 0;
+    };
+    auto step_euler = [&](Lane& L, int s) -> int {
+        hipStream_t st = L.st;
+        Prof p(c, VV_PROF_ELEMWISE, 0, 16.0 * L.Rc * M, st);
+        KCHK(c, vvk_cfg_euler(L.x, L.pred, MP, (int)L.Rc, M, g.cfg_strength, c->dt_host[s], L.row_src, st, &m__));
         return 0;
     };
 
     // Launch order: the lanes alternate block by block, so both streams always hold work and neither lane's enqueue waits for the
-    // other's queue to drain; the device orders each stream by itself.  Lane 1 forks from the caller's stream (what the caller
-    // enqueued before this call is visible to it) and joins back at the end (what the caller enqueues next sees both lanes).
-    if (n_lanes > 1) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));
-        for (int li = 1; li < n_lanes; ++li) HIPCHK(c, hipStreamWaitEvent(c->side_stream[li - 1], c->ev_fork, 0));
+    // other's queue to drain; the device orders each stream by itself.  Item lanes: lane 1 forks from the caller's stream once (what
+    // the caller enqueued before this call is visible to it) and joins back at the end (what the caller enqueues next sees both
+    // lanes).  Branch lanes: the same fork / join once per STEP, between the conditioning pack and the CFG combine.
+    Lane views[2];                                        // what the block-level kernels run on
+    int n_views = n_lanes;
+    if (branch_lanes) {
+        const Lane& L = lanes[0];
+        n_views = 2;
+        for (int v = 0; v < 2; ++v) {
+            Lane& V = views[v];
+            V = L;
+            const size_t r0 = v ? L.Rc : 0;             // the unconditional branch's rows follow the conditional branch's
+            V.st = v ? c->side_stream[0] : st;
+            V.R = L.Rc; V.n_seq = L.B; V.sum_sq = L.sum_sq / 2;
+            V.xcat += r0 * KP * es; V.h += r0 * D * es; V.h2 += r0 * D * es; V.h3 += r0 * D * es; V.att += r0 * D * es;
+            V.qkv += r0 * 3 * D * es; V.ffm += r0 * FF * es; V.xres += r0 * D; V.pred += r0 * MP;
+            V.csq_rows += r0 * 64; V.csk_rows += r0 * 64;
+            // row_start / kv_len: the conditional branch's entries serve both views (same lengths, rows relative to the view's base);
+            // row_pos: the first Rc entries (a row's position does not depend on its branch)
+        }
+    } else {
+        for (int li = 0; li < n_lanes; ++li) views[li] = lanes[li];
     }
+    auto fork = [&]() -> int {
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream[0], c->ev_fork, 0));
+        return 0;
+    };
+    auto join = [&]() {                                   // always reached, also after a failed launch: the side stream must not outlive the call
+        hipEventRecord(c->ev_join[0], c->side_stream[0]);
+        hipStreamWaitEvent(st, c->ev_join[0], 0);
+    };
     int rc = 0;
+    if (n_lanes > 1) rc = fork();
     for (int li = 0; li < n_lanes && !rc; ++li) rc = setup(lanes[li]);
     for (int s = step0; s < step0 + n_steps && !rc; ++s) {
-        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_head(lanes[li], s);
+        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_pack(lanes[li], s);
+        if (branch_lanes && !rc) rc = fork();
+        const bool forked = branch_lanes && !rc;
+        for (int v = 0; v < n_views && !rc; ++v) rc = step_head(views[v], s);
         for (int l = 0; l < g.depth && !rc; ++l)
-            for (int li = 0; li < n_lanes && !rc; ++li) rc = block(lanes[li], s, l);
-        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_tail(lanes[li], s);
+            for (int v = 0; v < n_views && !rc; ++v) rc = block(views[v], s, l);
+        for (int v = 0; v < n_views && !rc; ++v) rc = step_tail(views[v], s);
+        if (forked) join();
+        for (int li = 0; li < n_lanes && !rc; ++li) rc = step_euler(lanes[li], s);
     }
-    for (int li = 1; li < n_lanes; ++li) {                 // always join, also after a failed launch: no side stream may outlive the call
-        hipEventRecord(c->ev_join[li - 1], c->side_stream[li - 1]);
-        hipStreamWaitEvent(st, c->ev_join[li - 1], 0);
-    }
+    if (n_lanes > 1) join();
     return rc;
 }
 
