@@ -374,6 +374,24 @@ def test_two_lanes_equal_one_lane_bit_for_bit():
             xg, pcmg, leng = graph(d["noise"], pre)
             torch.cuda.synchronize()
             assert torch.equal(xg, x1) and torch.equal(pcmg, pcm1) and torch.equal(leng, len1), (dt, len(la), "graph")
+        # the table forms of the rope (standard tables read instead of computed; then gathered per packed row): the branch views offset
+        # the per-row tables by their first row, the item lanes build their own
+        for rope_rows in (0, 1):
+            eng.set_rope_theta(0.0)
+            eng.set_option("rope_rows", rope_rows)
+            for la, lt, gf in cases[:3]:
+                batch = make_batch(spec, la, lt, gf, seed=10 + len(la))
+                d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                lens = [int(v) for v in batch["seq_len"]]
+                pre = eng.preprocess(d["audio"], d["audio_len"], d["ids"], d["text_len"], d["seq_len"], d["N"], seq_len_host=lens)
+                xs = []
+                for lanes in (1, 2):
+                    eng.set_option("lanes", lanes)
+                    x = d["noise"].clone()
+                    eng.transformer_steps(x, pre, 0, 3)
+                    xs.append(x)
+                torch.cuda.synchronize()
+                assert torch.equal(xs[0], xs[1]), (dt, rope_rows, len(la))
         eng.set_option("lanes", 0)
         eng.close()
 
