@@ -480,7 +480,10 @@ def main():
     eng.prof_enable(True)
     was_graph, a.graph_steps = a.graph_steps, False       # events cannot be recorded inside a replayed graph: the profiled pass runs eagerly
     eng.set_option("lanes", 1)
+    torch.cuda.synchronize()
+    t_cls = time.perf_counter()
     step()
+    class_pass_ms = (time.perf_counter() - t_cls) * 1e3
     eng.set_option("lanes", lanes_opt)
     a.graph_steps = was_graph
     prof = eng.prof_collect()
@@ -555,8 +558,11 @@ def main():
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
         "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
     }
-    res["lanes"] = {"option": lanes_opt, "what": "Euler steps of a batch with >= 65,536 packed rows run as two half batches on two HIP streams (bit-identical "
-                    "results; tests/test_e2e_gpu.py::test_two_lanes_equal_one_lane_bit_for_bit); kernel_classes / rooflines: one-lane pass, each kernel alone"}
+    res["lanes"] = {"option": lanes_opt, "class_pass_ms": round(class_pass_ms, 2),
+                    "what": "timed steps: the Euler steps run as two lanes (half batches, or the two CFG branches of a single item) on two HIP streams, "
+                            "bit-identical to one lane (tests/test_e2e_gpu.py::test_two_lanes_equal_one_lane_bit_for_bit).  kernel_classes / rooflines: ONE extra "
+                            "untimed pass on one lane with HIP events around every launch (class_pass_ms: its wall time, which the class ms add up to) -- each "
+                            "kernel with the chip to itself; the two-lane step is shorter than that sum by the kernel tails the other lane fills"}
     if pcie_inclusive is not None:
         res["pcie_inclusive"] = pcie_inclusive
     res["devices"] = devices

@@ -310,6 +310,8 @@ def test_bench_json_contract():
     assert d["median_ms_per_step"] > 0 and "resident in HBM" in d["timed_region"] and "hbm_target_note" in d
     pi = d["pcie_inclusive"]                       # the same step with its PCIe legs, beside `value`, never as `value`
     assert pi["value"] > 0 and pi["steps"] >= 1 and "H2D" in pi["what"] and "D2H" in pi["what"]
+    ln = d["lanes"]                                # the class times come from a one-lane pass and add up to (at most) that pass's wall time
+    assert ln["option"] == 0 and ln["class_pass_ms"] > 0 and sum(v["ms"] for v in d["kernel_classes"].values()) <= ln["class_pass_ms"] * 1.02
 
 
 def test_bench_serve_workload_contract():
