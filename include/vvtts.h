@@ -163,7 +163,7 @@ VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
  * lane 1 on a context-owned stream forked from it at the start of the call and joined to it before the call returns (so the call
  * keeps its stream semantics, and can be captured into a hipGraph) -- so that one lane's kernel tails and launch gaps are filled by
  * the other's kernels.  A single item runs its two CFG branches (conditional / unconditional rows) as the lanes, forked and joined once
- * per Euler step.  0 (default) = for the bf16 model from 2,560 packed rows (2 x sum of the lengths) on, 1 = never, 2 = always.
+ * per Euler step.  0 (default) = for the bf16 model from 1,024 packed rows (2 x sum of the lengths) on, 1 = never, 2 = always.
  * Results are bit-identical: every row's arithmetic is independent of what shares its launch.
  * "pp_min_tiles": -1 (default) = vv_gemm's own choice between its persistent 256 x 256 kernel and the 128 x 128 one; n >= 0 = the
  * persistent kernel for every bf16 GEMM of the path with M >= 4096, N % 256 == 0 and >= n 256-tiles.  Same bits either way. */
@@ -195,7 +195,8 @@ typedef struct vv_gemm_args {
     int32_t n_store, seq_n, rope_dim;
     const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
     int32_t tile;   /* 0 = auto (bf16: the persistent 256x256 kernel when M >= 4096, N % 256 == 0 and the shape has at least one round of
-                       256-tiles for the chip's CUs or N >= 3072; fp32: 256x256 when M >= 4096 and N % 256 == 0), 128 or 256 to force */
+                       256-tiles for the chip's CUs or N >= 3072, below that 128x128 tiles or, for launches that do not fill the chip, 64-token x 128-feature
+                       tiles; fp32: 256x256 when M >= 4096 and N % 256 == 0), 128 or 256 to force (bf16: also 64).  Every bf16 choice gives the same bits */
     const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
     int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
                                   needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */
@@ -210,6 +211,8 @@ typedef struct vv_gemm_args {
                                   rounding of the roped value.  0 = read the tables (always in fp32) */
     int32_t rope_skip_q;       /* VV_EPI_QKV_ROPE: 1 = leave the q columns [0, rope_dim) un-roped (plain bias + store); the attention
                                   kernel ropes them while it loads Q (vv_attn_args.rope_cs_q).  The k columns are roped as always */
+    int32_t chip_share;        /* 0 / 1 = the launch has the chip to itself; 2 = it shares the chip with another stream of launches (the
+                                  two lanes of vv_transformer_steps): tile = 0 then prices its tilings for half of the CUs.  Speed only */
 } vv_gemm_args;
 VV_API int vv_gemm(vv_ctx* ctx, const vv_gemm_args* args, void* stream);
 /* The persistent bf16 GEMM walks ceil(tiles / CUs) rounds of 256x256 tiles; when the tile count leaves a partial last round, the

@@ -28,7 +28,7 @@ def gemm_tail_plan(eng, M, N, K):
 
 
 def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=None, ropes=None, seq_n=0, rope_dim=0, n_store=0, tile=0,
-         rope_pos=None, rope_by_row=0, tail=None, c_fill=0.0, rope_skip_q=0, rope_theta=0.0):
+         rope_pos=None, rope_by_row=0, tail=None, c_fill=0.0, rope_skip_q=0, rope_theta=0.0, chip_share=0):
     """A [M,K], W [N,K] on device, same dtype (bf16 or f32).  tail = (fp32 C_tail tensor [parts][M - row0][N], row0, parts): the
     split-K tail request.  c_fill: what a fresh output buffer holds before the launch (shows rows the kernel leaves unwritten)."""
     dt = rt.VV_BF16 if A.dtype == torch.bfloat16 else rt.VV_F32
@@ -51,6 +51,7 @@ def gemm(eng, A, W, bias=None, mode=0, act=0, out_dtype=None, gate=None, C_io=No
     a.rope_pos = None if rope_pos is None else rope_pos.data_ptr()
     a.rope_by_row = rope_by_row
     a.rope_skip_q = rope_skip_q
+    a.chip_share = chip_share
     a.rope_theta = rope_theta
     if tail is not None:
         a.C_tail, a.tail_row0, a.tail_parts = tail[0].data_ptr(), tail[1], tail[2]

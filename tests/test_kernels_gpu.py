@@ -558,6 +558,38 @@ def test_computed_rope_matches_the_tables(hip_tiny):
     assert torch.equal(attention(qkv, 0.125), attention(pre, 0.0))
 
 
+@pytest.mark.parametrize("M", [1600, 3200 + 77, 4800])
+def test_gemm_three_tilings_give_the_same_bits(hip_tiny, M):
+    """Round 4: vv_gemm picks among three bf16 tilings by launch size -- 64-token x 128-feature tiles (launches that do not fill the chip),
+    128 x 128, and the persistent 256 x 256 kernel -- and a row's result must not depend on the choice (an item alone and the same item
+    in a batch take different ones).  All three contract K in the same order with the same MFMA from bias-started accumulators and share
+    the epilogue arithmetic: plain store, tanh-GELU store, gate store and the computed-rope QKV epilogue are EQUAL arrays, ragged M
+    included (the last tile of each tiling is partial in a different place); and equal to what the automatic choice produces."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    dev = gu.DEV
+    g = torch.Generator().manual_seed(M)
+    K, N = 512, 1024
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    gate = torch.randn(N, generator=g).to(dev)
+    dummy = torch.zeros(1600, 64, device=dev)
+    ropes = [dummy, dummy, dummy, dummy]
+    forms = {"store": dict(), "gelu": dict(act=1), "gate": dict(mode=3, gate=gate),
+             "rope": dict(mode=1, ropes=ropes, seq_n=800, rope_dim=512, rope_theta=10000.0)}
+    y = A.float() @ W.float().t() + b
+    for name, kw in forms.items():
+        outs = {t: gu.gemm(eng, A, W, bias=b, tile=t, **kw) for t in (64, 128, 256, 0)}
+        outs["shared"] = gu.gemm(eng, A, W, bias=b, tile=0, chip_share=2, **kw)      # the automatic choice priced for half of the chip
+        for t in (128, 256, 0, "shared"):
+            assert torch.equal(outs[t], outs[64]), (name, t, float((outs[t].float() - outs[64].float()).abs().max()))
+        if name == "store":
+            assert gu.rel_err(outs[64], y) < TOL_BF16
+        if name == "gate":
+            assert gu.rel_err(outs[64], gate * y) < TOL_BF16
+
+
 def test_attention_spiked_max(hip_tiny):
     """Online-softmax rescale branch: a key late in the sequence dominates one query row."""
     rt, gu = _imports()

@@ -53,6 +53,7 @@ struct vv_ctx {
                                         // (22 LSB of PCM between two batchings of one text, tests/test_longform_gpu.py), and with the parts in
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
+    int chip_share = 1;                 // 2 while a call runs two lanes (vv_gemm_args.chip_share of its GEMM launches)
     int pp_min_tiles = -1;              // bf16 GEMMs of the path: -1 = the launcher's own choice between the persistent 256 x 256 kernel and the 128 x 128 one
                                         // (vv_gemm.hip launch(): about one full round of 256-tiles, or the wide QKV shape); n >= 0 = the persistent
                                         // kernel whenever M >= 4096, N % 256 == 0 and the shape has >= n 256-tiles (0 = the rule of rounds 1-3; lets a
@@ -159,6 +160,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
          void* C, int ldc, int M, int N, int K, hipStream_t st, const float* gate = nullptr, int n_store = 0,
          const float* const* rope = nullptr, int seq_n = 0, int rope_dim = 0, double alg_flops = -1, const int* rope_pos = nullptr,
          int rope_by_row = 0, void* c_tail = nullptr, int tail_row0 = 0, int tail_parts = 0, int rope_skip_q = 0, float rope_theta = 0.f) {
+    // (c->chip_share: 2 while vv_transformer_steps runs two lanes -- set around its launch loop)
     // rope: [cos_q, sin_q, cos_k, sin_k, compact_q, compact_k]
     vv_gemm_args g{};
     g.dtype = dtype; g.out_dtype = out_dtype; g.mode = mode; g.act = act;
@@ -167,6 +169,7 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     if (rope) { g.cos_q = rope[0]; g.sin_q = rope[1]; g.cos_k = rope[2]; g.sin_k = rope[3]; g.rope_cs_q = rope[4]; g.rope_cs_k = rope[5]; }
     g.rope_pos = rope_pos; g.rope_by_row = rope_by_row;
     g.C_tail = c_tail; g.tail_row0 = tail_row0; g.tail_parts = tail_parts; g.rope_skip_q = rope_skip_q; g.rope_theta = rope_theta;
+    g.chip_share = c->chip_share;
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     if (c->pp_min_tiles >= 0 && dtype == VV_DTYPE_BF16 && N % 256 == 0)
         g.tile = (M >= 4096 && (long long)((M + 255) / 256) * (N / 256) >= c->pp_min_tiles) ? 256 : 128;
@@ -459,8 +462,8 @@ int vv_preprocess_h(vv_ctx* c, int B, int N, const int16_t* audio, int ld_audio,
 // (profiles/r04/lanes_notes.md; three and four lanes, unequal cuts and CU-masked streams measured slower).  A lane is a complete
 // sub-problem: its own packed rows, row tables and buffers; the cut is the item boundary closest to half of the rows.
 namespace {
-constexpr size_t VV_LANE_MIN_ROWS = 2560;     // "lanes" auto: below ~2,500 packed rows the step is bound by the host's launch rate and a second stream of
-                                              // launches costs 1-2 % (profiles/r04/lanes_notes.md); above, two lanes win at every size measured
+constexpr size_t VV_LANE_MIN_ROWS = 1024;     // "lanes" auto: at ~600 packed rows the step is bound by the launch rate and a second stream of launches
+                                              // costs ~1 % (profiles/r04/lanes_notes.md); from 1,200 rows on two lanes win at every size measured
 struct Lane {
     int B = 0, b0 = 0;
     int n_seq = 0;                     // sequences the block kernels of this lane (or branch view) run on: 2 B, or B for one CFG branch
@@ -740,6 +743,7 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         hipStreamWaitEvent(st, c->ev_join[0], 0);
     };
     int rc = 0;
+    c->chip_share = n_views;
     if (n_lanes > 1) rc = fork();
     for (int li = 0; li < n_lanes && !rc; ++li) rc = setup(lanes[li]);
     for (int s = step0; s < step0 + n_steps && !rc; ++s) {
@@ -754,6 +758,7 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
         for (int li = 0; li < n_lanes && !rc; ++li) rc = step_euler(lanes[li], s);
     }
     if (n_lanes > 1) join();
+    c->chip_share = 1;
     return rc;
 }
 

@@ -147,17 +147,21 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
 }
 
 template <typename T, int MODE, typename To, int CFG>
-__global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 ? 4 : 2) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
+__global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 ? 4 : (CFG == 3 ? 3 : 2)) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
                                                                   int ldw, To* __restrict__ C, int ldc, int M, int N, int K,
                                                                   EpiArgs e, int m_tiles, int n_tiles) {
     constexpr int BK = GemmTraits<T>::BK;
-    constexpr bool BIG = CFG != 0;
-    constexpr int BT = BIG ? 256 : 128;            // tile edge (rows of A and rows of W)
-    constexpr int TILE_BYTES = BT * 128;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-    constexpr int MW = CFG == 1 ? 128 : 64;        // tokens per wave
+    // CFG 0: 128 x 128 tile, 4 waves (64 tokens x 64 features each); 1 / 2: 256 x 256 with 8 / 16 waves; 3 (bf16 only): 64 tokens x 128
+    // features, 4 waves of 32 x 64 -- twice the workgroups for launches whose 128-tiles do not fill the chip (single utterances)
+    constexpr bool BIG = CFG == 1 || CFG == 2;
+    constexpr int BT = BIG ? 256 : 128;            // rows of W (features) per tile
+    constexpr int BTM = CFG == 3 ? 64 : BT;        // rows of A (tokens) per tile
+    constexpr int A_BYTES = BTM * 128, W_BYTES = BT * 128;
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int MW = CFG == 1 ? 128 : (CFG == 3 ? 32 : 64);        // tokens per wave
     constexpr int NWAVE = CFG == 2 ? 16 : (CFG == 1 ? 8 : 4);
-    constexpr int PPW = BT / 8 / NWAVE;            // LDS-DMA pieces per wave per tile
+    constexpr int PPA = BTM / 8 / NWAVE, PPW = BT / 8 / NWAVE;       // LDS-DMA pieces per wave per tile (A, W)
+    static_assert(CFG != 3 || sizeof(T) == 2, "the 64-token tile exists for bf16 only");
     // (a four-stage ring with counted waits, one workgroup per CU, was measured SLOWER for the single-utterance shapes than this
     // two-stage loop at two workgroups per CU: 97.9 against 94.1 ms of GEMM per utterance, profiles/r03/gemm_notes.md)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | W tile)
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
     const int mt = (L / n_tiles) * 8 + xcd;
     const int nt = L % n_tiles;
     if (mt >= m_tiles) return;
-    const int bm = mt * BT, bn = nt * BT;
+    const int bm = mt * BTM, bn = nt * BT;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,26 +179,28 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
     const int wc = BIG ? (wave & 3) : (wave & 1);
 
     // ---- staging: a tile is BT/8 LDS-DMA pieces (8 rows x 128 B); every wave issues PPW pieces of each tile
-    const char* a_src[PPW];
+    const char* a_src[PPA];
     const char* w_src[PPW];
 #pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-        const int q = wave * PPW + u;
-        const int row = q * 8 + (lane >> 3);
+    for (int u = 0; u < PPA; ++u) {
+        const int row = (wave * PPA + u) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         const int gm = min(bm + row, M - 1);          // clamp: rows >= M are computed but never stored
         a_src[u] = (const char*)A + (size_t)gm * lda * sizeof(T) + c * 16;
+    }
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int row = (wave * PPW + u) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
         w_src[u] = (const char*)W + (size_t)(bn + row) * ldw * sizeof(T) + c * 16;
     }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * BK * sizeof(T);
 #pragma unroll
-        for (int u = 0; u < PPW; ++u) {
-            const int q = wave * PPW + u;
-            glds16(a_src[u] + koff, base + q * 1024);
-            glds16(w_src[u] + koff, base + TILE_BYTES + q * 1024);
-        }
+        for (int u = 0; u < PPA; ++u) glds16(a_src[u] + koff, base + (wave * PPA + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) glds16(w_src[u] + koff, base + A_BYTES + (wave * PPW + u) * 1024);
     };
 
     const int nk = K / BK;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         for (int kt = 0; kt < nk; ++kt) {
             ring_step(kt);
             const char* sa = smem + (kt % NST) * STAGE_BYTES;
-            const char* sw = sa + TILE_BYTES;
+            const char* sw = sa + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 wf[4], af[MI];
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         for (int kt = 0; kt < nk; ++kt) {
             ring_step(kt);
             const char* sa = smem + (kt % NST) * STAGE_BYTES;
-            const char* sw = sa + TILE_BYTES;
+            const char* sw = sa + A_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 // lane half h takes chunk 2kk+h: the k pairing {4(2kk)+j, 4(2kk+1)+j} is the same for both operands
@@ -971,12 +977,13 @@ hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, in
 template <typename T, int MODE, typename To, int CFG>
 hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                     hipStream_t st) {
-    constexpr int BT = CFG ? 256 : 128;
-    constexpr int LDS = 2 * 2 * BT * 128;
+    constexpr int BT = (CFG == 1 || CFG == 2) ? 256 : 128;
+    constexpr int BTM = CFG == 3 ? 64 : BT;
+    constexpr int LDS = 2 * (BT + BTM) * 128;
     static KernelSetup setup;
     auto kern = gemm_kernel<T, MODE, To, CFG>;
     if (hipError_t he = setup.ensure((const void*)kern, LDS, nullptr); he != hipSuccess) return he;
-    const int m_tiles = (M + BT - 1) / BT, n_tiles = N / BT;
+    const int m_tiles = (M + BTM - 1) / BTM, n_tiles = N / BT;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
     kern<<<grid, CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), LDS, st>>>((const T*)A, lda, (const T*)W, ldw, (To*)C, ldc, M, N, K, e, m_tiles, n_tiles);
     return hipGetLastError();
@@ -984,14 +991,17 @@ hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int
 
 template <typename T, int MODE, typename To>
 hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
-                  hipStream_t st, int force_tile) {
+                  hipStream_t st, int force_tile, int chip_share) {
     bool big = force_tile == 256 || (force_tile == 0 && M >= 4096 && N % 256 == 0);
     if constexpr (sizeof(T) == 2) {
         // auto: below one full round of 256 x 256 tiles the persistent kernel leaves CUs idle for its whole length and the 128 x 128
         // kernel (four times the tiles, two workgroups per CU) is faster -- out-projection / FF2 up to M = 12,800, FF1 up to 6,400 --
         // except for the wide QKV shape, where the persistent kernel wins from M = 4,096 on (profiles/r04/gemm_tile_by_m.txt).  Both
         // kernels produce the same bits (one arithmetic, tests/test_kernels_gpu.py), so the choice is speed only.
-        if (force_tile == 0 && big && N < 3072 && (long long)((M + 255) / 256) * (N / 256) < device_cus()) big = false;
+        // A launch that shares the chip with another lane's launches (chip_share 2) is priced for its share: alone the 128 x 128 kernel wins
+        // by reaching more CUs, beside another stream of kernels those CUs are busy anyway and the persistent kernel's lower cost per
+        // flop decides (two lanes of 6,400 / 12,800 rows: -4.8 % / -4 % of the step with the threshold at CUs / 2, profiles/r04/lanes_notes.md).
+        if (force_tile == 0 && big && N < 3072 && (long long)((M + 255) / 256) * (N / 256) < device_cus() / (chip_share == 2 ? 2 : 1)) big = false;
         // bf16 throughput path: ping-pong kernel.  Its buffer resources carry a 31-bit num_records, so operands of 2 GiB or
         // more take the plain-pointer kernels below (64-bit addressing) instead of reading zeros past the resource end.
         if (big && pp_fits(M, N, K, lda, ldw, ldc, sizeof(To), e.act))
@@ -999,6 +1009,21 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
     }
     if (e.ks > 1) return hipErrorInvalidValue;                 // a split-K tail exists in the persistent kernel only (vvk_gemm checks)
     if (big) return launch_t<T, MODE, To, 2>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    if constexpr (sizeof(T) == 2) {
+        // 64-token tiles (three workgroups per CU) when they need no more rounds of workgroups than the 128 x 128 tiles (two per CU) would:
+        // launches that do not fill the chip -- every GEMM of a single utterance's CFG branch (M = 1,600: block sum 88 -> 73 us), the
+        // N = 1024 shapes up to M = 4,800 -- run 8 - 29 % shorter; all 24 measured (shape, M) pairs agree with the rule
+        // (profiles/r04/gemm_tile64_by_m.txt).  Same bits: only the token rows of a tile change.
+        bool t64 = force_tile == 64;
+        if (force_tile == 0) {
+            // (a launch that shares the chip with another lane's launches is priced for its share: what 64-token tiles gain by reaching
+            // idle CUs the other lane's kernels fill anyway, while their extra operand traffic stays -- M = 3,200 lanes: +3 % with the
+            // whole-chip rule, -2 ... -5 % with this one, profiles/r04/lanes_small_shapes*.txt)
+            const long long t = (long long)((M + 127) / 128) * (N / 128), cus = device_cus() / (chip_share == 2 ? 2 : 1);
+            t64 = t <= 3 * cus && (2 * t + 3 * cus - 1) / (3 * cus) <= (t + 2 * cus - 1) / (2 * cus);
+        }
+        if (t64) return launch_t<T, MODE, To, 3>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
+    }
     return launch_t<T, MODE, To, 0>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
 }
 
@@ -1019,7 +1044,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (((size_t)g->lda * esz) % 16 || ((size_t)g->ldw * esz) % 16 || ((uintptr_t)g->A % 16) || ((uintptr_t)g->W % 16) ||
         ((uintptr_t)g->C % 16) || (g->ldc % 4)) { *err = "gemm: operands must be 16-byte aligned"; return -22; }
     if (g->lda < g->K || g->ldw < g->K) { *err = "gemm: leading dimension smaller than K"; return -22; }
-    if (g->tile != 0 && g->tile != 128 && g->tile != 256) { *err = "gemm: tile must be 0 (auto), 128 or 256"; return -22; }
+    if (g->tile != 0 && g->tile != 128 && g->tile != 256 && !(g->tile == 64 && g->dtype == VV_BF16)) { *err = "gemm: tile must be 0 (auto), 128, 256, or 64 (bf16)"; return -22; }
     if (g->tile == 256 && g->N % 256) { *err = "gemm: the 256 tile needs N % 256 == 0"; return -22; }
     EpiArgs e{};                 // value-initialised: a field this function forgets is zero, never stack garbage
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
@@ -1062,7 +1087,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (g->mode == MODE_GATE_RES && g->out_dtype != VV_F32) { *err = "gemm: residual stream is fp32"; return -22; }
     const bool bf = g->dtype == VV_BF16, obf = g->out_dtype == VV_BF16;
     hipError_t he = hipSuccess;
-#define GO(T, MODE, To) he = launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st, g->tile)
+#define GO(T, MODE, To) he = launch<T, MODE, To>(g->A, g->lda, g->W, g->ldw, g->C, g->ldc, g->M, g->N, g->K, e, st, g->tile, g->chip_share)
     if (g->mode == MODE_STORE) {
         if (bf && obf) GO(bf16, MODE_STORE, bf16);
         else if (bf) GO(bf16, MODE_STORE, float);

@@ -51,7 +51,7 @@ class vv_gemm_args(C.Structure):
                 ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
                 ("n_store", C.c_int32), ("seq_n", C.c_int32), ("rope_dim", C.c_int32),
                 ("rope_cs_q", C.c_void_p), ("rope_cs_k", C.c_void_p), ("tile", C.c_int32), ("rope_pos", C.c_void_p), ("rope_by_row", C.c_int32),
-                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p), ("rope_theta", C.c_float), ("rope_skip_q", C.c_int32)]
+                ("tail_parts", C.c_int32), ("tail_row0", C.c_int32), ("C_tail", C.c_void_p), ("rope_theta", C.c_float), ("rope_skip_q", C.c_int32), ("chip_share", C.c_int32)]
 
 
 class vv_attn_args(C.Structure):
