@@ -320,16 +320,23 @@ VV_API int vv_rope_compact(vv_ctx* ctx, const float* cos_t, const float* sin_t, 
 VV_API int vv_rope_rows(vv_ctx* ctx, const float* compact, const int32_t* pos, float* out, int rows, void* stream);
 VV_API int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* stream);
 
-/* ---- reference-clip ingest on the device.  Together they replace the arithmetic of
- * AudioProcessor.load_audio after decoding (reference core/audio_processor.py:16-44: set_frame_rate, then
- * normalize_to_int16 = remove DC, peak -> 29491, truncate). */
-/* polyphase FIR resampler: y[n] = sum_i x[i] * taps[(n + skip) * down - i * up], f64 accumulate, f32 out.
- * taps = host-designed low-pass already scaled by `up` (f64, device). */
+/* ---- reference-clip ingest on the device (a8 + SURVEY 8(f) N3).  Together they replace the arithmetic of
+ * AudioProcessor.load_audio after RIFF parsing (reference core/audio_processor.py:15-44): pydub's set_channels(1) =
+ * audioop.tomono(.., 0.5, 0.5), set_frame_rate = audioop.ratecv(.., None), float32 conversion, then normalize_to_int16 =
+ * remove DC (numpy's float32 mean, in numpy's summation order), peak -> 29491, truncate.  Bit-exact to stdlib audioop + numpy. */
+/* pcm = the clips' interleaved little-endian signed PCM bytes, back to back (each clip 4-byte aligned); desc = n_clips x 8 int64
+ * (device): {byte offset, sample width 1|2|4, channels, n_frames, src_rate / g, dst_rate / g, out offset (floats), n_out} with
+ * g = gcd(src_rate, dst_rate) and n_out = (n_frames - 1) * (dst_rate / g) / (src_rate / g) + 1 (= n_frames at equal rates).
+ * out[out offset + m] = float32 of the mono sample m at the destination rate.  max_out = the largest n_out. */
+VV_API int vv_ingest_pcm(vv_ctx* ctx, const void* pcm, const int64_t* desc, int n_clips, int64_t max_out, float* out, void* stream);
+/* opt-in, NOT the reference's arithmetic: polyphase FIR resampler y[n] = sum_i x[i] * taps[(n + skip) * down - i * up],
+ * f64 accumulate, f32 out.  taps = host-designed low-pass already scaled by `up` (f64, device). */
 VV_API int vv_resample_poly(vv_ctx* ctx, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip,
                      float* y, int n_out, void* stream);
 /* n_clips mono f32 clips stored back to back, clip i = [offsets[i], offsets[i+1]); out has the same offsets.
- * stats = 2 * n_clips doubles of device scratch. */
-VV_API int vv_normalize_clips(vv_ctx* ctx, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats,
+ * scratch = vv_normalize_scratch_bytes(n_clips, offsets[n_clips]) bytes of device memory; clips shorter than 2^24 samples. */
+VV_API size_t vv_normalize_scratch_bytes(int n_clips, int64_t total_len);
+VV_API int vv_normalize_clips(vv_ctx* ctx, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, void* scratch,
                        int16_t* out, void* stream);
 
 #ifdef __cplusplus

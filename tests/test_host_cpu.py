@@ -301,7 +301,7 @@ def test_batching_frontend_plumbing(cpu_engine):
 def test_resample_design_formula_matches_host_mirror():
     """N3, CPU side: the polyphase formula the GPU resampler evaluates (y[n] = sum_i x[i] * taps[(n + skip) * down - i * up], taps
     and skip from voice_bank.resample_design) reproduces the host mirror's resampler for the common source rates."""
-    from vietvoice_tts_amd.core.audio_processor import _resample
+    from vietvoice_tts_amd.core.audio_processor import _resample_polyphase as _resample
     from vietvoice_tts_amd.voice_bank import resample_design
     rng = np.random.default_rng(4)
     for src in (48000, 44100, 22050, 16000, 8000):

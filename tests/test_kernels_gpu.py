@@ -1090,33 +1090,13 @@ def test_groupnorm(hip_tiny, B, Cc, T, G):
     assert gu.rel_err(y, ref64) < 2e-3          # the INPUT's fp32 rounding at 300 +- 0.03 already costs ~1e-3 of the normalised value
 
 
-# ------------------------------------------------------------------ N3: reference-clip ingest on the device
-def test_normalize_clips_matches_reference_arithmetic(hip_tiny):
-    """vv_normalize_clips vs the host mirror of normalize_to_int16 (pinned by the reference-generated golden vectors in
-    tests/test_host_cpu.py::test_normalize_golden).  The mean is reduced in another order than numpy's pairwise sum, so a
-    sample that lands within one f32 ulp of an integer may truncate differently: <= 1 LSB, on a vanishing fraction."""
-    import torch
-    from vietvoice_tts_amd.core import AudioProcessor
-    eng = hip_tiny["f32"]
-    rng = np.random.default_rng(5)
-    clips = [(rng.standard_normal(n) * s + o).astype(np.float32) for n, s, o in ((1, 1.0, 0.0), (77, 3000.0, 120.0), (24000, 0.1, 0.0), (191999, 9000.0, -400.0))]
-    clips.append(np.zeros(500, np.float32))                              # silent clip: peak 0 -> passes through
-    clips.append(np.full(300, 7.0, np.float32))                          # pure DC
-    off = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
-    out = eng.normalize_clips(torch.from_numpy(np.concatenate(clips)).cuda(), torch.from_numpy(off).cuda()).cpu().numpy()
-    for j, c in enumerate(clips):
-        want = AudioProcessor.normalize_to_int16(c)
-        got = out[off[j]: off[j + 1]]
-        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (j, d.max(), (d > 0).mean())
-
-
+# ------------------------------------------------------------------ N3: opt-in polyphase resampler (the default ingest is in test_ingest_gpu.py)
 @pytest.mark.parametrize("src", [48000, 16000, 44100, 22050])
 def test_resample_poly_matches_host_mirror(hip_tiny, src):
-    """vv_resample_poly vs the host mirror's polyphase resampler (core/audio_processor.py::_resample; the reference uses
-    pydub's set_frame_rate, absent offline -- that deviation is documented in DESIGN.md, and this parity is GPU-vs-host-mirror)."""
+    """vv_resample_poly vs the host's polyphase resampler (core/audio_processor.py::_resample_polyphase).  Opt-in only: the
+    default ingest is the reference's audioop arithmetic (tests/test_ingest_gpu.py); this parity is GPU-vs-host-mirror."""
     import torch
-    from vietvoice_tts_amd.core.audio_processor import _resample
+    from vietvoice_tts_amd.core.audio_processor import _resample_polyphase as _resample
     from vietvoice_tts_amd.voice_bank import resample_design
     eng = hip_tiny["f32"]
     rng = np.random.default_rng(src)

@@ -3,25 +3,44 @@
 truncation (:28-44), clip repair (:46-58), linear cross-fade (:69-120), RMS-matched cos^2 cross-fade
 (:122-192).  Pinned by tests/golden/host_golden.npz (generated from the reference functions).
 
-Container I/O differs by necessity: the reference decodes any format through pydub/ffmpeg (:15-26)
-and writes WAVEX through soundfile (:60-67); neither exists here, so ``load_audio`` reads RIFF/WAVE
-(PCM 8/16/24/32-bit, float32/64) natively, averages channels and resamples with a polyphase filter,
-and ``save_audio`` writes a WAVE_FORMAT_EXTENSIBLE PCM16 file by hand.
+``load_audio`` (:15-26) is ``AudioSegment.from_file(..).set_channels(1).set_frame_rate(sr)`` followed by
+``get_array_of_samples`` -> float32 -> ``normalize_to_int16``.  pydub (pin: >=0.25.0, pyproject.toml:38) is absent
+offline; for RIFF/WAVE PCM input its two calls are integer arithmetic of CPython's stdlib ``audioop``
+(pydub/audio_segment.py ``set_channels``: ``audioop.tomono(data, width, 0.5, 0.5)``; ``set_frame_rate``:
+``audioop.ratecv(data, width, channels, src, dst, None)``), restated here in closed form with numpy:
+
+  tomono : floor(l * 0.5 + r * 0.5)                                    = (l + r) >> 1
+  ratecv : output m sits at input position m * I / O (I, O = rates / gcd); with n1 = ceil(m * I / O),
+           d = n1 * O - m * I in [0, O):  out = trunc((x32[n1 - 1] * d + x32[n1] * (O - d)) / O) >> (32 - 8 * width)
+           (x32 = sample << (32 - 8 * width), x32[-1] = 0; products, sum and the truncated quotient are exact in
+           float64 for the 16-bit case and O < 65536, where the whole expression equals floor((p * d + c * (O - d)) / O));
+           floor((N - 1) * O / I) + 1 outputs for N input frames.
+
+Bit-exact against stdlib ``audioop`` (tests/test_ingest_cpu.py, tests/golden/ingest_golden.npz) for widths 1, 2, 4.
+pydub's own glue is restated from its published source and is "parity unpinned": 8-bit WAV is unsigned and gets
+``audioop.bias(-128)``; 24-bit samples are widened to 32 bit with the sign byte written FIRST (value * 256 + 0x00 / 0xFF);
+more than two channels are mixed as ``sum(sample // channels)``.  Float WAVE goes through ffmpeg in the reference
+(``-acodec pcm_s32le``): restated as ``clip(llrint(x * 2**31))`` and unpinned; other containers need ffmpeg and are
+out of scope.  ``save_audio`` writes a WAVE_FORMAT_EXTENSIBLE PCM16 file by hand (soundfile 'WAVEX' bytes unpinned).
+The polyphase resampler of earlier rounds stays available as an explicit opt-in (``resampler="polyphase"``).
 """
 from __future__ import annotations
 
 import io
 import struct
+from math import gcd
 from pathlib import Path
 from typing import List, Tuple, Union
 
 import numpy as np
 
 _PCM_GUID = bytes.fromhex("0100000000001000800000aa00389b71")
+_INT_OF_WIDTH = {1: np.int8, 2: np.int16, 4: np.int32}
 
 
-def _parse_wav(data: bytes) -> Tuple[np.ndarray, int]:
-    """-> (float32 samples scaled like int16, mono), sample_rate."""
+def _decode_wav(data: bytes) -> Tuple[np.ndarray, int, int]:
+    """RIFF/WAVE bytes -> (frames (n_frames, channels) of int8 / int16 / int32, sample width in bytes, rate): the
+    samples pydub's AudioSegment holds after ``from_file`` (see the module docstring for the 8- / 24-bit / float glue)."""
     if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
         raise ValueError("unsupported audio container: only RIFF/WAVE can be decoded in this build (no ffmpeg)")
     pos, fmt, pcm = 12, None, None
@@ -33,39 +52,83 @@ def _parse_wav(data: bytes) -> Tuple[np.ndarray, int]:
         elif cid == b"data":
             pcm = body
         pos += 8 + size + (size & 1)
-    if fmt is None or pcm is None:
+    if fmt is None or pcm is None or len(fmt) < 16:
         raise ValueError("malformed WAVE file: missing fmt or data chunk")
     tag, ch, rate, _br, _ba, bits = struct.unpack("<HHIIHH", fmt[:16])
     if tag == 0xFFFE and len(fmt) >= 26:
         tag = struct.unpack("<H", fmt[24:26])[0]
+    if ch < 1 or rate < 1:
+        raise ValueError("malformed WAVE file: zero channels or rate")
     if tag == 1:
         if bits == 8:
-            x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) * 256.0
+            x, width = (np.frombuffer(pcm, dtype=np.uint8) ^ 0x80).view(np.int8), 1          # audioop.bias(data, 1, -128)
         elif bits == 16:
-            x = np.frombuffer(pcm[: len(pcm) // 2 * 2], dtype="<i2").astype(np.float32)
+            x, width = np.frombuffer(pcm[: len(pcm) // 2 * 2], dtype="<i2"), 2
         elif bits == 24:
-            b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
-            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-            v = np.where(v >= 1 << 23, v - (1 << 24), v)
-            x = v.astype(np.float32) / 256.0
+            b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3)
+            w = np.empty((b.shape[0], 4), np.uint8)
+            w[:, 0] = np.where(b[:, 2] > 0x7F, 0xFF, 0x00)                                     # pydub writes the pad byte first
+            w[:, 1:] = b
+            x, width = w.reshape(-1).view("<i4"), 4
         elif bits == 32:
-            x = np.frombuffer(pcm[: len(pcm) // 4 * 4], dtype="<i4").astype(np.float32) / 65536.0
+            x, width = np.frombuffer(pcm[: len(pcm) // 4 * 4], dtype="<i4"), 4
         else:
             raise ValueError(f"unsupported PCM width {bits}")
-    elif tag == 3:
-        dt = "<f4" if bits == 32 else "<f8"
-        x = np.frombuffer(pcm[: len(pcm) // (bits // 8) * (bits // 8)], dtype=dt).astype(np.float32) * 32768.0
+    elif tag == 3 and bits in (32, 64):
+        f = np.frombuffer(pcm[: len(pcm) // (bits // 8) * (bits // 8)], dtype="<f4" if bits == 32 else "<f8").astype(np.float64)
+        x, width = np.clip(np.rint(np.nan_to_num(f) * 2147483648.0), -2147483648.0, 2147483647.0).astype(np.int32), 4
     else:
         raise ValueError(f"unsupported WAVE format tag {tag}")
-    if ch > 1:
-        x = x[: len(x) // ch * ch].reshape(-1, ch).mean(axis=1)
-    return np.ascontiguousarray(x, dtype=np.float32), int(rate)
+    x = x.astype(_INT_OF_WIDTH[width], copy=False)
+    return np.ascontiguousarray(x[: len(x) // ch * ch].reshape(-1, ch)), width, int(rate)
 
 
-def _resample(x: np.ndarray, src: int, dst: int) -> np.ndarray:
+def tomono(frames: np.ndarray) -> np.ndarray:
+    """(n, channels) integer frames -> (n,) mono, pydub ``set_channels(1)``: 2 channels = audioop.tomono(.., 0.5, 0.5)
+    (floor of the half sum), more = sum of floor-divided samples (OverflowError like pydub's array arithmetic when the
+    floors add up below the range: only with every channel at negative full scale)."""
+    ch = frames.shape[1]
+    if ch == 1:
+        return frames[:, 0]
+    if ch == 2:
+        return ((frames[:, 0].astype(np.int64) + frames[:, 1].astype(np.int64)) >> 1).astype(frames.dtype)
+    mixed = (frames.astype(np.int64) // ch).sum(axis=1)
+    info = np.iinfo(frames.dtype)
+    if mixed.size and (mixed.min() < info.min or mixed.max() > info.max):     # pydub accumulates in an array.array of the width
+        raise OverflowError("channel mix does not fit the sample width (every channel at negative full scale)")
+    return mixed.astype(frames.dtype)
+
+
+def ratecv_len(n_in: int, src: int, dst: int) -> int:
+    """Frames audioop.ratecv(.., state=None) emits for n_in input frames."""
+    if n_in <= 0:
+        return 0
+    g = gcd(src, dst)
+    return (n_in - 1) * (dst // g) // (src // g) + 1
+
+
+def ratecv(x: np.ndarray, src: int, dst: int) -> np.ndarray:
+    """Mono integer samples at ``src`` Hz -> ``dst`` Hz, audioop.ratecv(data, width, 1, src, dst, None) (weights 1, 0):
+    linear interpolation between the two neighbouring input samples, evaluated in float64 on the samples shifted to
+    32 bit exactly as Modules/audioop.c does, truncated, shifted back."""
+    if src == dst or x.size == 0:                      # pydub returns the segment itself / skips empty data
+        return x
+    g = gcd(src, dst)
+    I, O = src // g, dst // g
+    shift = 32 - 8 * x.dtype.itemsize
+    m = np.arange(ratecv_len(x.size, src, dst), dtype=np.int64)
+    n1 = (m * I + O - 1) // O
+    d = (n1 * O - m * I).astype(np.float64)
+    x32 = (x.astype(np.int64) << shift).astype(np.float64)
+    prev = np.where(n1 > 0, x32[np.maximum(n1 - 1, 0)], 0.0)
+    out = ((prev * d + x32[n1] * (float(O) - d)) / float(O)).astype(np.int64)        # C (int) cast: truncation
+    return (out >> shift).astype(x.dtype)
+
+
+def _resample_polyphase(x: np.ndarray, src: int, dst: int) -> np.ndarray:
+    """Opt-in band-limited resampler (NOT the reference's arithmetic)."""
     if src == dst or x.size == 0:
         return x
-    from math import gcd
     from scipy.signal import resample_poly
     g = gcd(src, dst)
     return resample_poly(x.astype(np.float64), dst // g, src // g).astype(np.float32)
@@ -75,23 +138,39 @@ class AudioProcessor:
     """Static helpers, same names and semantics as the reference class."""
 
     @staticmethod
-    def _read(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int]:
+    def _read_bytes(path_or_bytes: Union[str, bytes]) -> bytes:
         if isinstance(path_or_bytes, str):
             if not Path(path_or_bytes).exists():
                 raise FileNotFoundError(f"Audio file not found: {path_or_bytes}")
             with open(path_or_bytes, "rb") as fh:
-                return _parse_wav(fh.read())
-        return _parse_wav(bytes(path_or_bytes))
+                return fh.read()
+        return bytes(path_or_bytes)
+
+    @staticmethod
+    def decode(path_or_bytes: Union[str, bytes]) -> Tuple[np.ndarray, int, int]:
+        """-> (integer frames (n, channels), sample width, rate); container parsing only, no arithmetic on samples."""
+        return _decode_wav(AudioProcessor._read_bytes(path_or_bytes))
 
     @staticmethod
     def probe_duration(path_or_bytes: Union[str, bytes]) -> float:
-        x, rate = AudioProcessor._read(path_or_bytes)
-        return len(x) / float(rate)
+        frames, _w, rate = AudioProcessor.decode(path_or_bytes)
+        return frames.shape[0] / float(rate)
 
     @staticmethod
-    def load_audio(path_or_bytes: Union[str, bytes], sample_rate: int) -> np.ndarray:
-        x, rate = AudioProcessor._read(path_or_bytes)
-        return AudioProcessor.normalize_to_int16(_resample(x, rate, sample_rate))
+    def load_samples(path_or_bytes: Union[str, bytes], sample_rate: int) -> np.ndarray:
+        """The integer samples ``audio_segment.get_array_of_samples()`` holds in the reference (:22-25): mono, at sample_rate."""
+        frames, _w, rate = AudioProcessor.decode(path_or_bytes)
+        return ratecv(tomono(frames), rate, sample_rate)
+
+    @staticmethod
+    def load_audio(path_or_bytes: Union[str, bytes], sample_rate: int, resampler: str = "ratecv") -> np.ndarray:
+        if resampler == "ratecv":
+            return AudioProcessor.normalize_to_int16(AudioProcessor.load_samples(path_or_bytes, sample_rate).astype(np.float32))
+        if resampler != "polyphase":
+            raise ValueError(f"unknown resampler {resampler!r}")
+        frames, _w, rate = AudioProcessor.decode(path_or_bytes)
+        x = frames.astype(np.float32).mean(axis=1)              # the normalisation below is scale-free
+        return AudioProcessor.normalize_to_int16(_resample_polyphase(x, rate, sample_rate))
 
     @staticmethod
     def normalize_to_int16(audio: np.ndarray) -> np.ndarray:

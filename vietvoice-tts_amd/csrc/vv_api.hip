@@ -1050,8 +1050,12 @@ int vv_rope_compact(vv_ctx* c, const float* cos_t, const float* sin_t, float* ou
 int vv_resample_poly(vv_ctx* c, const float* x, int n_in, const double* taps, int n_taps, int up, int down, int skip, float* y, int n_out, void* st) {
     SINGLE(c, vvk_resample_poly(x, n_in, taps, n_taps, up, down, skip, y, n_out, (hipStream_t)st, &m__));
 }
-int vv_normalize_clips(vv_ctx* c, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, double* stats, int16_t* out, void* st) {
-    SINGLE(c, vvk_normalize_clips(x, (const long long*)offsets, n_clips, (long long)max_len, stats, out, (hipStream_t)st, &m__));
+int vv_ingest_pcm(vv_ctx* c, const void* pcm, const int64_t* desc, int n_clips, int64_t max_out, float* out, void* st) {
+    SINGLE(c, vvk_ingest_pcm(pcm, (const long long*)desc, n_clips, (long long)max_out, out, (hipStream_t)st, &m__));
+}
+size_t vv_normalize_scratch_bytes(int n_clips, int64_t total_len) { return vvk_normalize_scratch_bytes(n_clips, (long long)total_len); }
+int vv_normalize_clips(vv_ctx* c, const float* x, const int64_t* offsets, int n_clips, int64_t max_len, void* scratch, int16_t* out, void* st) {
+    SINGLE(c, vvk_normalize_clips(x, (const long long*)offsets, n_clips, (long long)max_len, scratch, out, (hipStream_t)st, &m__));
 }
 int vv_cfg_euler(vv_ctx* c, float* x, const float* pred, int ldp, int BN, int n_mel, float cfg, float dt, void* st) {
     SINGLE(c, vvk_cfg_euler(x, pred, ldp, BN, n_mel, cfg, dt, nullptr, (hipStream_t)st, &m__));

@@ -45,7 +45,9 @@ int vvk_row_tables(const int* seq_len, int B, int N, int Rc, int* row_start, int
 int vvk_silu(float* x, size_t n, hipStream_t st, const char** err);
 int vvk_resample_poly(const float* x, int n_in, const double* h, int n_taps, int up, int down, int skip, float* y, int n_out,
                       hipStream_t st, const char** err);
-int vvk_normalize_clips(const float* x, const long long* off, int n_clips, long long max_len, double* stats, int16_t* out,
+int vvk_ingest_pcm(const void* pcm, const long long* desc, int n_clips, long long max_out, float* out, hipStream_t st, const char** err);
+size_t vvk_normalize_scratch_bytes(int n_clips, long long total_len);
+int vvk_normalize_clips(const float* x, const long long* off, int n_clips, long long max_len, void* scratch, int16_t* out,
                         hipStream_t st, const char** err);
 int vvk_cast(int dtype, const float* in, void* out, size_t n, hipStream_t st, const char** err);
 int vvk_rope_compact(const float* c, const float* s, float* out, int n, hipStream_t st, const char** err);

@@ -137,6 +137,8 @@ EXPORTS = {
     "vv_rope_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vv_cfg_euler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "vv_resample_poly": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vv_ingest_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vv_normalize_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "vv_normalize_clips": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -396,14 +398,25 @@ class HipSynth:
                                                   y.data_ptr(), n_out, self._stream()))
         return y
 
-    def normalize_clips(self, x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
-        """x f32 [total] = clips back to back, offsets int64 [n+1] (device) -> int16 [total] (DC removed, peak 29491)."""
+    def ingest_pcm(self, pcm: torch.Tensor, desc: torch.Tensor, max_out: int, total_out: int) -> torch.Tensor:
+        """pcm uint8 [bytes] (clips' interleaved PCM back to back) and desc int64 [n, 8] on the device (include/vvtts.h) ->
+        f32 [total_out]: mono samples at the destination rate (audioop.tomono + audioop.ratecv arithmetic)."""
+        assert pcm.is_cuda and pcm.dtype == torch.uint8 and pcm.is_contiguous() and desc.is_cuda and desc.dtype == torch.int64 and desc.is_contiguous()
+        assert desc.dim() == 2 and desc.shape[1] == 8
+        y = torch.empty((total_out,), dtype=torch.float32, device=self.device)
+        with self._lock, torch.cuda.device(self.device):
+            self._check(self.lib.vv_ingest_pcm(self.ctx, pcm.data_ptr(), desc.data_ptr(), desc.shape[0], max_out, y.data_ptr(), self._stream()))
+        return y
+
+    def normalize_clips(self, x: torch.Tensor, offsets: torch.Tensor, max_len: int = 0) -> torch.Tensor:
+        """x f32 [total] = clips back to back, offsets int64 [n+1] (device) -> int16 [total] (DC removed, peak 29491);
+        max_len = the longest clip when the caller knows it (else the total is taken as the bound)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int64
         n = offsets.numel() - 1
         out = torch.empty((x.numel(),), dtype=torch.int16, device=self.device)
-        stats = torch.empty((2 * n,), dtype=torch.float64, device=self.device)
+        scratch = torch.empty((int(self.lib.vv_normalize_scratch_bytes(n, x.numel())),), dtype=torch.uint8, device=self.device)
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, x.numel(), stats.data_ptr(),
+            self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, int(max_len) or x.numel(), scratch.data_ptr(),
                                                     out.data_ptr(), self._stream()))
         return out
 

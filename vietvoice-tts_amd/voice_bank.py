@@ -1,13 +1,16 @@
-"""Device-resident voice bank: reference clips are decoded once, resampled + DC/peak-normalised
-ON THE GPU, and kept in HBM keyed by content, so a request for a known voice costs a dictionary lookup.
+"""Device-resident voice bank: reference clips are decoded once, mixed to mono, rate-converted and
+DC/peak-normalised ON THE GPU with the reference's own arithmetic, and kept in HBM keyed by content, so a request for a
+known voice costs a dictionary lookup.
 
 The reference re-opens the model tar, re-decodes and re-normalises the clip on every call
-(core/model.py:204-211, core/audio_processor.py:16-44) and carries an unused ``sample_cache``
+(core/model.py:204-211, core/audio_processor.py:15-44) and carries an unused ``sample_cache``
 (core/tts_engine.py:30).  Here:
 
-  host   : RIFF/WAVE byte parsing (no arithmetic), FIR design for the resampler (a few hundred taps)
-  device : polyphase resampling (vv_resample_poly), mean / peak / scale / int16 truncation (vv_normalize_clips),
-           clips of one ``ingest_many`` call batched on grid.y
+  host   : RIFF/WAVE byte parsing (no arithmetic on samples), one descriptor row per clip
+  device : vv_ingest_pcm  = pydub set_channels(1) / set_frame_rate = audioop.tomono + audioop.ratecv, -> float32
+           vv_normalize_clips = numpy-ordered float32 mean / peak / scale / int16 truncation
+           -- bit-exact to AudioProcessor.load_audio (tests/test_ingest_gpu.py); clips of one ``ingest_many`` call batched on grid.y
+  opt-in : ``resampler="polyphase"`` keeps the band-limited FIR of earlier rounds (vv_resample_poly; not the reference's arithmetic)
 
 An entry keeps the int16 clip on the device (what vv_preprocess reads) plus one host copy (what the reference-style
 session path and the duration model read).  LRU eviction by a byte budget; 239 built-in voices of ~8 s are ~90 MB.
@@ -49,8 +52,10 @@ class VoiceEntry:
 
 
 class VoiceBank:
-    def __init__(self, synth, sample_rate: int, max_bytes: int = 1 << 30):
-        self.synth, self.sample_rate, self.max_bytes = synth, int(sample_rate), int(max_bytes)
+    def __init__(self, synth, sample_rate: int, max_bytes: int = 1 << 30, resampler: str = "ratecv"):
+        if resampler not in ("ratecv", "polyphase"):
+            raise ValueError(f"unknown resampler {resampler!r}")
+        self.synth, self.sample_rate, self.max_bytes, self.resampler = synth, int(sample_rate), int(max_bytes), resampler
         self._entries: "OrderedDict[str, VoiceEntry]" = OrderedDict()
         self._by_host: Dict[int, VoiceEntry] = {}
         self._taps = {}
@@ -91,23 +96,15 @@ class VoiceBank:
                 self.hits += 1                    # repeated inside this call: ingested once
         if todo:
             dev = self.synth.device
-            clips = []
-            for k, it in todo.items():
-                x, rate = AudioProcessor._read(it)                     # host: container parsing only
-                xd = torch.from_numpy(x).to(dev)
-                if rate != self.sample_rate and x.size:
-                    if rate not in self._taps:
-                        taps, up, down, skip = resample_design(rate, self.sample_rate)
-                        self._taps[rate] = (torch.from_numpy(taps).to(dev), up, down, skip)
-                    taps, up, down, skip = self._taps[rate]
-                    n_out = -(-(x.size * up) // down)
-                    xd = self.synth.resample_poly(xd, taps, up, down, skip, n_out)
-                clips.append(xd)
-            lens = [int(c.numel()) for c in clips]
-            if any(n == 0 for n in lens):
+            decoded = [AudioProcessor.decode(it) for it in todo.values()]          # host: container parsing only
+            if any(f.shape[0] == 0 for f, _w, _r in decoded):
                 raise ValueError("empty audio clip")
+            if self.resampler == "ratecv":
+                x, lens = self._ingest_ratecv(decoded, dev)
+            else:
+                x, lens = self._ingest_polyphase(decoded, dev)
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            pcm = self.synth.normalize_clips(torch.cat(clips) if len(clips) > 1 else clips[0], torch.from_numpy(off).to(dev))
+            pcm = self.synth.normalize_clips(x, torch.from_numpy(off).to(dev), max_len=max(lens))
             host = pcm.cpu().numpy()
             for j, k in enumerate(todo):
                 e = VoiceEntry(k, pcm[off[j]: off[j + 1]].clone(), host[off[j]: off[j + 1]].copy())
@@ -123,6 +120,43 @@ class VoiceBank:
                 self._by_host.pop(id(old.pcm_host), None)
                 self.bytes -= old.nbytes
         return [self._entries[k] for k in keys]
+
+    def _ingest_ratecv(self, decoded, dev):
+        """One vv_ingest_pcm launch for all clips: interleaved PCM bytes back to back (4-byte aligned) + descriptor rows."""
+        import torch
+        from .core.audio_processor import ratecv_len
+        parts, desc, pos, out_pos = [], [], 0, 0
+        from .core.audio_processor import tomono
+        for frames, width, rate in decoded:
+            if frames.shape[1] > 2:
+                tomono(frames)                    # range check only (OverflowError like the reference); the mix itself runs on the device
+            raw = frames.tobytes()
+            g = gcd(rate, self.sample_rate)
+            n_out = ratecv_len(frames.shape[0], rate, self.sample_rate) if rate != self.sample_rate else frames.shape[0]
+            desc.append([pos, width, frames.shape[1], frames.shape[0], rate // g, self.sample_rate // g, out_pos, n_out])
+            pad = -len(raw) % 4
+            parts.append(raw + b"\0" * pad)
+            pos += len(raw) + pad
+            out_pos += n_out
+        buf = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).to(dev)
+        lens = [d[7] for d in desc]
+        x = self.synth.ingest_pcm(buf, torch.tensor(desc, dtype=torch.int64).to(dev), max(lens), out_pos)
+        return x, lens
+
+    def _ingest_polyphase(self, decoded, dev):
+        import torch
+        clips = []
+        for frames, _w, rate in decoded:
+            x = frames.astype(np.float32).mean(axis=1)
+            xd = torch.from_numpy(x).to(dev)
+            if rate != self.sample_rate:
+                if rate not in self._taps:
+                    taps, up, down, skip = resample_design(rate, self.sample_rate)
+                    self._taps[rate] = (torch.from_numpy(taps).to(dev), up, down, skip)
+                taps, up, down, skip = self._taps[rate]
+                xd = self.synth.resample_poly(xd, taps, up, down, skip, -(-(x.size * up) // down))
+            clips.append(xd)
+        return (torch.cat(clips) if len(clips) > 1 else clips[0]), [int(c.numel()) for c in clips]
 
     def clear(self):
         self._entries.clear()
