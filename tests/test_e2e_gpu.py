@@ -330,6 +330,18 @@ def test_captured_step_loop_and_decode_equal_eager():
             eng._check(eng.lib.vv_transformer_steps_into(eng.ctx, 3, d["N"], d["seq_len"].data_ptr(), graphs._host, x_e.data_ptr(), pre["cat_mel_text"].data_ptr(),
                                                          pre["cat_mel_text_drop"].data_ptr(), eng.rope[0].data_ptr(), eng.rope[1].data_ptr(), eng.rope[2].data_ptr(),
                                                          eng.rope[3].data_ptr(), 0, 1, graphs.ws.data_ptr(), 4096, torch.cuda.current_stream().cuda_stream))
+        # the capture bakes in pointers to the context's time-grid tables; set_nfe frees them -> a replay must refuse
+        assert not graphs.stale()
+        eng.set_nfe(8)
+        assert graphs.stale()
+        with pytest.raises(RuntimeError, match="stale"):
+            graphs(d["noise"], pre)
+        fresh = eng.capture_steps(len(la), d["N"], lens, batch["t_gen_max"])          # capturing again on the new grid works
+        x_e = d["noise"].clone()
+        eng.transformer_steps(x_e, pre, 0, eng.n_steps)
+        x_g, _pcm, _len = fresh(d["noise"], pre)
+        torch.cuda.synchronize()
+        assert torch.equal(x_g, x_e)
         eng.close()
 
 

@@ -65,6 +65,66 @@ def test_engine_session_io_contract_and_errors(tmp_path):
     e.cleanup()
 
 
+def test_transformer_session_reads_fed_rope_tables_per_call(tmp_path):
+    """the bf16 model computes the standard rope angles, but a session is FED its tables (reference I/O contract,
+    core/tts_engine.py:161-170).  Non-standard tables on ANY call (not only the first) are read for that call and only for it:
+    the result equals an engine switched to table reads, and the next standard-table call is the computed form again."""
+    import torch
+    from vietvoice_tts_amd.core import ModelConfig, TTSEngine
+    cfg = ModelConfig(model_cache_dir=str(tmp_path), synthetic_model=True, model_spec="tiny", nfe_step=5, acoustic_dtype="bf16")
+    e = TTSEngine(cfg)
+    m = e.model_session_manager
+    eng = m.engine
+    ref, txt = m.select_sample()
+    audio, ids, max_dur, ts = e._prepare_inputs(ref, txt, "Xin chào các bạn.")[0]
+    outs = e._run_preprocess(audio, ids, max_dur)
+    ses = m.sessions["transformer"]
+    run = lambda tabs: ses.run(m.output_names["transformer"], dict(zip(m.input_names["transformer"], [outs[0]] + tabs + [outs[5], outs[6], ts])))[0]
+    std = [np.ascontiguousarray(o) for o in outs[1:5]]
+    first = run(std)
+    odd = [np.ascontiguousarray(t[:, ::-1].copy()) for t in std]                     # positions reversed: valid tables, not the standard ones
+    got_odd = run(odd)                                                               # second call of this session
+    assert not np.array_equal(got_odd, first)
+    with eng.reading_rope_tables():                                                  # what reading those tables gives
+        x = torch.from_numpy(outs[0].copy()).to(eng.device)
+        n = x.shape[1]
+        up = lambda a: torch.from_numpy(a).to(eng.device).reshape(n, -1)
+        pre = {"rope_cos_q": up(odd[0]), "rope_sin_q": up(odd[1]), "rope_cos_k": up(odd[2]), "rope_sin_k": up(odd[3]),
+               "cat_mel_text": torch.from_numpy(outs[5]).to(eng.device), "cat_mel_text_drop": torch.from_numpy(outs[6]).to(eng.device),
+               "seq_len": torch.tensor([n], dtype=torch.int32, device=eng.device)}
+        eng.transformer_steps(x, pre, 0, 1)
+    assert np.array_equal(got_odd, x.cpu().numpy())
+    assert np.array_equal(run(std), first)                                           # mode restored: computed angles again, same bits
+    e.cleanup()
+
+
+def test_lone_clip_between_half_and_full_fft_runs_end_to_end(tmp_path):
+    """_prepare_inputs admits clips of n_fft/2 + 1 samples, vv_preprocess wants an audio plane of at least n_fft columns.
+    A request whose ONLY clip is that short used to fail on the GPU path with a generic error: the plane is padded now (device path
+    and session path), the item's own length still bounds what the mel front end reads, and both paths agree."""
+    from vietvoice_tts_amd.core import AudioProcessor
+    e = _engine(tmp_path)
+    n_fft = e.model_session_manager.spec.n_fft
+    rng = np.random.default_rng(2)
+    for n in (n_fft // 2 + 1, n_fft - 1):
+        clip = AudioProcessor.to_wav_bytes((rng.standard_normal(n) * 5000).astype(np.int16), 24000)
+        ins = e._prepare_inputs(clip, "a", "Xin chào.")
+        assert ins[0][0].shape[-1] == n
+        import torch
+        blk = [torch.randn((int(ins[0][2][0]), 100), generator=torch.Generator().manual_seed(n))]
+        w_dev = e._synthesize_device(ins, noise_blocks=blk)[0].reshape(-1)
+        outs = e._run_preprocess(*ins[0][:3])
+        assert int(outs[7][0]) == n // 256 + 1
+        noise = blk[0].numpy()[None]
+        m = e.model_session_manager
+        ts = ins[0][3]
+        for _ in range(e.config.nfe_step - 1):
+            noise, ts = m.sessions["transformer"].run(m.output_names["transformer"], dict(zip(m.input_names["transformer"], [noise] + list(outs[1:7]) + [ts])))
+        w_ses = e._run_decode(noise, outs[7]).reshape(-1)
+        assert w_dev.size == w_ses.size > 0 and int(np.abs(w_dev.astype(np.int32) - w_ses.astype(np.int32)).max()) <= 2
+    e.cleanup()
+
+
 def test_streaming_equals_buffered_on_device(tmp_path):
     """N4: streamed blocks concatenate to the buffered PCM (same seed, one chunk per GPU wave vs all chunks in one batch:
     ragged batching must not change a sequence's result beyond the fp32 summation-order tolerance)."""

@@ -518,3 +518,65 @@ def test_batching_frontend_close_drains_and_refuses(cpu_engine):
         late = fe.submit("Xin chào.")
         with pytest.raises(RuntimeError, match="front end is closed"):
             late.result(timeout=5)
+
+
+def test_batching_frontend_stage_failure_never_strands_a_future(cpu_engine, monkeypatch):
+    """a stage that dies on an unexpected exception still forwards the end-of-stream sentinel and fails the
+    batch in hand, so every Future completes and close() returns quickly instead of waiting out its joins."""
+    import time
+    import torch
+    from vietvoice_tts_amd.batching import BatchingFrontend
+    # (a) the noise draw fails for one request: only that request fails, the next one is served
+    fe = BatchingFrontend(cpu_engine, max_wait_ms=20.0, max_requests=4)
+    real = torch.randn
+    calls = {"n": 0}
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            raise MemoryError("synthetic failure in the noise draw")
+        return real(*a, **k)
+    monkeypatch.setattr(torch, "randn", flaky)
+    bad = fe.submit("Xin chào.")
+    with pytest.raises(RuntimeError, match="Speech synthesis failed: synthetic failure"):
+        bad.result(timeout=60)
+    monkeypatch.setattr(torch, "randn", real)
+    assert fe.submit("Xin chào.").result(timeout=120)[0].size > 0
+    fe.close()
+    # (b) the collector itself dies: queued requests fail, the stages behind shut down, close() is quick, submit refuses
+    monkeypatch.setattr(BatchingFrontend, "_collect", lambda self: (_ for _ in ()).throw(OSError("synthetic collector failure")))
+    fe = BatchingFrontend(cpu_engine, max_wait_ms=20.0, max_requests=4)
+    f1 = fe.submit("một")
+    t0 = time.time()
+    fe.close()
+    assert time.time() - t0 < 30 and f1.done()
+    with pytest.raises(RuntimeError, match="synthetic collector failure|closed"):
+        f1.result(timeout=5)
+    with pytest.raises(RuntimeError, match="closed"):
+        fe.submit("hai").result(timeout=5)
+    monkeypatch.undo()
+    # (b2) the stage dies of a non-Exception while preparing: every request it had taken off the queue fails, none is stranded
+    fe = BatchingFrontend(cpu_engine, max_wait_ms=200.0, max_requests=4)
+    monkeypatch.setattr(fe, "_prepare_one", lambda req, batch: (_ for _ in ()).throw(SystemExit(3)))
+    futs = [fe.submit("một"), fe.submit("hai")]
+    for f in futs:
+        with pytest.raises(RuntimeError, match="Speech synthesis failed"):
+            f.result(timeout=60)
+    t0 = time.time()
+    fe.close()
+    assert time.time() - t0 < 30
+    # (c) the cross-fade stage fails on a batch: its requests fail, later batches are still served
+    fe = BatchingFrontend(cpu_engine, max_wait_ms=20.0, max_requests=4)
+    orig = BatchingFrontend._finish
+    state = {"first": True}
+
+    def finish_once_broken(self, batch, waves, err):
+        if state["first"]:
+            state["first"] = False
+            raise ValueError("synthetic finisher failure")
+        return orig(self, batch, waves, err)
+    monkeypatch.setattr(BatchingFrontend, "_finish", finish_once_broken)
+    with pytest.raises(RuntimeError, match="synthetic finisher failure"):
+        fe.submit("ba").result(timeout=120)
+    assert fe.submit("bốn").result(timeout=120)[0].size > 0
+    fe.close()

@@ -50,7 +50,7 @@ class BatchingFrontend:
         self._done: "queue.Queue" = queue.Queue()                # synthesised batches waiting for their cross-fades
         self._serial = 0
         self._serial_lock = threading.Lock()
-        self._stop = False
+        self._closed = False           # close() has been called: submit() refuses (set under _serial_lock)
         self._closing = False          # the close() sentinel has been taken off the request queue
         self.batches_run = 0
         self.requests_done = 0
@@ -70,14 +70,14 @@ class BatchingFrontend:
         """voice: gender / group / area / emotion / sample_iteration / reference_audio / reference_text.
         ``serial`` fixes the request's noise stream (default: arrival counter)."""
         fut: Future = Future()
-        if self._stop:
-            fut.set_exception(RuntimeError("Speech synthesis failed: the batching front end is closed"))
-            return fut
-        with self._serial_lock:
+        with self._serial_lock:           # close() raises `_closed` under the same lock: a request is either queued in front of the
+            if self._closed:              # sentinel (and served) or refused here -- never orphaned behind it
+                fut.set_exception(RuntimeError("Speech synthesis failed: the batching front end is closed"))
+                return fut
             if serial is None:
                 serial = self._serial
             self._serial = max(self._serial, serial) + 1
-        self._q.put((serial, text, speed, voice, fut))
+            self._q.put((serial, text, speed, voice, fut))
         return fut
 
     def synthesize(self, text: str, speed: Optional[float] = None, **voice) -> Tuple[np.ndarray, float]:
@@ -86,10 +86,13 @@ class BatchingFrontend:
     def close(self):
         """Drain and stop: requests submitted before the call are still served (the sentinel queues up behind them); a request that
         could not be (a stage died, the join timed out) gets an exception instead of a Future that never completes."""
-        self._q.put(None)
+        with self._serial_lock:
+            if self._closed:
+                return
+            self._closed = True
+            self._q.put(None)
         for t in self._threads:
             t.join(timeout=120)
-        self._stop = True
         while True:
             try:
                 req = self._q.get_nowait()
@@ -120,11 +123,16 @@ class BatchingFrontend:
         except Exception as e:
             fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
             return
-        n_mel = eng.model_session_manager.spec.n_mel
-        gen = torch.Generator().manual_seed(eng.config.random_seed * 1000003 + serial)
+        try:
+            n_mel = eng.model_session_manager.spec.n_mel
+            gen = torch.Generator().manual_seed(eng.config.random_seed * 1000003 + serial)
+            blocks = [torch.randn((int(i[2][0]), n_mel), generator=gen, dtype=torch.float32) for i in inputs]
+        except Exception as e:          # noqa: BLE001  (nothing of this request has entered the batch yet)
+            fut.set_exception(RuntimeError(f"Speech synthesis failed: {e}"))
+            return
         batch.plans.append((fut, len(inputs)))
         batch.flat.extend(inputs)
-        batch.blocks.extend(torch.randn((int(i[2][0]), n_mel), generator=gen, dtype=torch.float32) for i in inputs)
+        batch.blocks.extend(blocks)
         batch.n_req += 1
 
     def _collect(self) -> Optional[_Batch]:
@@ -150,20 +158,56 @@ class BatchingFrontend:
                 break
             reqs.append(nxt)
         batch = _Batch()
-        for r in reqs:
-            self._prepare_one(r, batch)
+        for k, r in enumerate(reqs):
+            try:
+                self._prepare_one(r, batch)
+            except BaseException as e:    # noqa: BLE001  (_prepare_one reports its own failures; this is the last line of defence)
+                if not r[4].done():
+                    r[4].set_exception(RuntimeError(f"Speech synthesis failed: {e!r}"))
+                if not isinstance(e, Exception):          # the stage is going down: nothing taken off the queue may be left pending
+                    for later in reqs[k + 1:]:
+                        later[4].set_exception(RuntimeError(f"Speech synthesis failed: {e!r}"))
+                    self._fail(batch, e)
+                    raise
         return batch
 
+    @staticmethod
+    def _fail(batch: Optional[_Batch], err) -> None:
+        if batch is not None:
+            for fut, _n in batch.plans:
+                if not fut.done():
+                    fut.set_exception(RuntimeError(f"Speech synthesis failed: {err}"))
+
     def _prep_loop(self):
+        self._in_hand = None
+        try:
+            self._prep_body()
+        except BaseException as e:        # noqa: BLE001  (the batch being handed over dies with the stage, loudly)
+            self._closing = True
+            self._fail(self._in_hand, e)
+            self._drain_requests(e)
+            if not isinstance(e, Exception):
+                raise
+        finally:
+            self._ready.put(None)          # whatever happened here, the stages behind must see the end of the stream
+
+    def _prep_body(self):
         while True:
-            batch = self._collect()
+            try:
+                batch = self._collect()
+            except Exception as e:        # noqa: BLE001  (an unexpected failure while collecting: stop taking requests)
+                self._closing = True
+                self._drain_requests(e)
+                return
             if batch is None:
                 break
+            self._in_hand = batch
             # hand over; while the GPU stage still has a batch waiting in front, keep filling this one (a collected batch is always
             # delivered, also when close() arrives meanwhile)
             while batch.flat:
                 try:
                     self._ready.put(batch, timeout=0.002)
+                    self._in_hand = None
                     break
                 except queue.Full:
                     pass
@@ -176,7 +220,15 @@ class BatchingFrontend:
                         self._closing = True
                     else:
                         self._prepare_one(nxt, batch)
-        self._ready.put(None)
+
+    def _drain_requests(self, err) -> None:
+        while True:
+            try:
+                req = self._q.get_nowait()
+            except queue.Empty:
+                return
+            if req is not None and not req[4].done():
+                req[4].set_exception(RuntimeError(f"Speech synthesis failed: {err}"))
 
     # ------------------------------------------------------------------ stage 2: the GPU
     def _run_batch(self, batch: _Batch):
@@ -194,15 +246,19 @@ class BatchingFrontend:
         return waves
 
     def _gpu_loop(self):
-        while True:
-            batch = self._ready.get()
-            if batch is None:
-                break
-            try:
-                self._done.put((batch, self._run_batch(batch), None))
-            except Exception as e:        # noqa: BLE001
-                self._done.put((batch, None, e))
-        self._done.put(None)
+        try:
+            while True:
+                batch = self._ready.get()
+                if batch is None:
+                    break
+                try:
+                    self._done.put((batch, self._run_batch(batch), None))
+                except BaseException as e:        # noqa: BLE001
+                    self._done.put((batch, None, e))
+                    if not isinstance(e, Exception):
+                        raise
+        finally:
+            self._done.put(None)
 
     # ------------------------------------------------------------------ stage 3: cross-fade + completion
     def _finish(self, batch: _Batch, waves, err) -> None:
@@ -228,7 +284,10 @@ class BatchingFrontend:
             item = self._done.get()
             if item is None:
                 break
-            self._finish(*item)
+            try:
+                self._finish(*item)
+            except Exception as e:        # noqa: BLE001  (never leave a Future of the batch in hand pending)
+                self._fail(item[0], e)
 
     # ------------------------------------------------------------------ overlap=False: the three stages in order on one thread
     def _serial_loop(self):

@@ -64,10 +64,13 @@ class HipSession:
         vals = [feed[n] for n in self._in]
         if self.kind == "preprocess":
             audio = torch.from_numpy(np.ascontiguousarray(np.asarray(vals[0]).reshape(1, -1))).to(torch.int16).to(dev)
+            n_audio = audio.shape[1]
+            if n_audio < eng.spec.n_fft:                       # plane at least n_fft wide (vv_preprocess's contract); the tail is never read
+                audio = torch.nn.functional.pad(audio, (0, eng.spec.n_fft - n_audio))
             ids = torch.from_numpy(np.ascontiguousarray(np.asarray(vals[1]).reshape(1, -1))).to(torch.int32).to(dev)
             n = int(np.asarray(vals[2]).reshape(-1)[0])
             i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=dev)
-            pre = eng.preprocess(audio, i32(audio.shape[1]), ids, i32(ids.shape[1]), i32(n), n)
+            pre = eng.preprocess(audio, i32(n_audio), ids, i32(ids.shape[1]), i32(n), n, audio_len_host=[n_audio])
             noise = torch.randn((1, n, eng.spec.n_mel), generator=self.noise_gen, dtype=torch.float32)
             res = {"noise": noise.numpy(), "ref_signal_len": pre["ref_signal_len"].cpu().numpy().astype(np.int64)}
             for k in ("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k"):
@@ -84,17 +87,21 @@ class HipSession:
                    "cat_mel_text": up(vals[5]), "cat_mel_text_drop": up(vals[6]),
                    "seq_len": torch.tensor([n], dtype=torch.int32, device=dev)}
             # The bf16 model computes the standard rope angles instead of reading the tables (vv_set_rope_theta).  This session takes
-            # its tables from the CALLER (the reference's I/O contract, core/tts_engine.py:161-170): if they are not the standard ones
-            # this engine produces in its preprocess stage, fall back to reading them -- never ignore what was fed.
-            if not getattr(self, "_rope_checked", False):
-                same = all(torch.equal(pre[k_], eng.rope[i][:n]) for i, k_ in enumerate(("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k")))
-                if not same:
-                    logger.warning("transformer session: non-standard rope tables fed; the tables are read instead of computed")
-                    eng.set_rope_theta(0.0)
-                self._rope_checked = True
+            # its tables from the CALLER (the reference's I/O contract, core/tts_engine.py:161-170): whenever they are not the standard
+            # ones this engine produces in its preprocess stage, THIS call reads them -- never ignore what was fed, and never change
+            # the mode for other sessions of the engine.  Checked on every call (four small device compares).
+            same = n <= eng.rope[0].shape[0] and all(pre[k_].shape == eng.rope[i][:n].shape and torch.equal(pre[k_], eng.rope[i][:n])
+                                                     for i, k_ in enumerate(("rope_cos_q", "rope_sin_q", "rope_cos_k", "rope_sin_k")))
             step = int(np.asarray(vals[7]).reshape(-1)[0])
             k = min(self.fuse_nfe, eng.n_steps - step)
-            eng.transformer_steps(x, pre, step, k)
+            if same:
+                eng.transformer_steps(x, pre, step, k)
+            else:
+                if not getattr(self, "_rope_warned", False):
+                    logger.warning("transformer session: non-standard rope tables fed; the tables are read instead of computed")
+                    self._rope_warned = True
+                with eng.reading_rope_tables():
+                    eng.transformer_steps(x, pre, step, k)
             return [x.cpu().numpy(), np.array([step + k], dtype=np.int32)]
         x = torch.from_numpy(np.ascontiguousarray(vals[0], dtype=np.float32)).to(dev)
         n = x.shape[1]

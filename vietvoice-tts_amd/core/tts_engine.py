@@ -181,7 +181,9 @@ class TTSEngine:
             B = len(group)
             lens_a = np.array([g[0].shape[-1] for g in group], dtype=np.int32)
             lens_t = np.array([g[1].shape[1] for g in group], dtype=np.int32)
-            S, T = int(lens_a.max()), int(lens_t.max())
+            # the audio plane is at least n_fft wide (vv_preprocess's contract): a lone clip of n_fft/2 + 1 ... n_fft - 1 samples is
+            # admitted by _prepare_inputs, its zeros past audio_len are never read (the mel front end reflects inside audio_len)
+            S, T = max(int(lens_a.max()), int(spec.n_fft)), int(lens_t.max())
             ids = np.zeros((B, T), dtype=np.int32)
             for i, g in enumerate(group):
                 ids[i, : lens_t[i]] = g[1][0]

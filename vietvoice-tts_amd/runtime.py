@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import contextlib
 import threading
 from typing import Dict, Optional, Tuple
 
@@ -215,7 +216,7 @@ class HipSynth:
         self.spec = spec
         self.device = torch.device(device)
         self.dt_code, self.dt_torch = _dt(acoustic_dtype)
-        self._lock = threading.Lock()        # one stream of calls per context (reference: api/tts_engine.py:64-67)
+        self._lock = threading.RLock()       # one stream of calls per context (reference: api/tts_engine.py:64-67); re-entrant: reading_rope_tables
         self.ctx = C.c_void_p()
         cfg = cfg_from_spec(spec)
         idx = self.device.index if self.device.index is not None else 0
@@ -241,6 +242,7 @@ class HipSynth:
         # angles in the QKV epilogue instead of reading them (vv_set_rope_theta; the fp32 model reads the tables either way)
         self._check(self.lib.vv_set_rope_theta(self.ctx, float(spec.rope_theta)))
         self.nfe_step = None
+        self.grid_generation = 0         # bumped by whatever a captured Euler-step graph has baked in (time grid, rope mode, options)
         self.set_nfe(nfe_step)
 
     # ------------------------------------------------------------------ plumbing
@@ -274,6 +276,7 @@ class HipSynth:
             self._check(self.lib.vv_set_time_grid(self.ctx, sinus.data_ptr(), dtc.data_ptr(), int(t.numel()), self._stream()))
         self.nfe_step = nfe_step
         self.n_steps = int(t.numel())
+        self.grid_generation += 1        # vv_set_time_grid frees and reallocates the tables a captured step graph points into
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, audio: torch.Tensor, audio_len: torch.Tensor, text_ids: torch.Tensor, text_len: torch.Tensor,
@@ -424,10 +427,26 @@ class HipSynth:
         """theta > 1: the rope tables of this engine are the standard ones of that base, the bf16 QKV epilogue computes the angles;
         0: the tables are read (vv_set_rope_theta)."""
         self._check(self.lib.vv_set_rope_theta(self.ctx, float(theta)))
+        self._rope_theta = float(theta)
+        self.grid_generation = getattr(self, "grid_generation", 0) + 1
+
+    @contextlib.contextmanager
+    def reading_rope_tables(self):
+        """For ONE caller's calls: the rope tables handed to transformer_steps are read, not recomputed from theta (a session that
+        is fed non-standard tables).  Holds the engine lock, so no other call and no graph replay sees the switched mode; the
+        previous mode is restored on exit (captured graphs stay valid: none can run in between)."""
+        with self._lock:
+            prev = getattr(self, "_rope_theta", 0.0)
+            self._check(self.lib.vv_set_rope_theta(self.ctx, 0.0))
+            try:
+                yield
+            finally:
+                self._check(self.lib.vv_set_rope_theta(self.ctx, prev))
 
     def set_option(self, name: str, value: int):
         """Context switches of the C ABI (vv_set_option), e.g. ``fuse_mrf`` 0/1."""
         self._check(self.lib.vv_set_option(self.ctx, name.encode(), int(value)))
+        self.grid_generation += 1
 
     # ------------------------------------------------------------------ profiling
     def prof_enable(self, on: bool):
@@ -521,6 +540,12 @@ class GraphedSteps:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._launch()
+        # the captured launches hold device pointers into the context's time-grid tables and its step count, rope mode and lane
+        # plan: anything that changes those (HipSynth.set_nfe / set_rope_theta / set_option) makes this graph stale
+        self.generation = eng.grid_generation
+
+    def stale(self) -> bool:
+        return self.generation != self.eng.grid_generation
 
     def _launch(self):
         e = self.eng
@@ -536,6 +561,9 @@ class GraphedSteps:
     def __call__(self, noise: torch.Tensor, pre: Dict[str, torch.Tensor]):
         """noise [B,N,n_mel] and ``pre`` (HipSynth.preprocess of the same batch) -> (x, pcm, pcm_len): views of the static buffers,
         valid until the next call."""
+        if self.stale():
+            raise RuntimeError("captured Euler-step graph is stale: the engine's time grid, rope mode or an option changed after the "
+                               "capture (set_nfe / set_rope_theta / set_option); capture again with HipSynth.capture_steps")
         with self.eng._lock:
             self.x.copy_(noise)
             self.cat.copy_(pre["cat_mel_text"])
