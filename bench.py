@@ -433,6 +433,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_busy_s = sum(step_s)                              # this rank's own step time, without the waits at the barriers
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -463,10 +464,12 @@ def main():
         audio_s_all = audio_s_rank
 
     devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(local)}"]
+    rows_rank = int(sum(int(b[0]["seq_len"].sum()) for b in batches))
+    per_rank = [{"rank": rank, "ms_per_step": round(rank_busy_s / a.steps * 1e3, 2), "units": nb, "rows": rows_rank, "audio_s": round(audio_s_rank, 3)}]
     if dist is not None:                                  # which card every rank ran on (two ranks on one card = a rehearsal, and says so)
         got = [None] * world
-        dist.all_gather_object(got, devices[0])
-        devices = got
+        dist.all_gather_object(got, (devices[0], per_rank[0]))
+        devices, per_rank = [g_[0] for g_ in got], [g_[1] for g_ in got]
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -497,7 +500,7 @@ def main():
     # file names the program it was taken over ("how_short"), and that string is what traffic_source reports.
     traffic, traffic_src = None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for rel in ("profiles/r04/gemm_pmc_traffic.json", "profiles/r03/gemm_pmc_traffic.json", "profiles/r02/gemm_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
+    for rel in ("profiles/r05/gemm_pmc_traffic.json", "profiles/r04/gemm_pmc_traffic.json", "profiles/r03/gemm_pmc_traffic.json", "profiles/r02/gemm_pmc_traffic.json", "profiles/r01/gemm_pmc_traffic.json"):
         tf = os.path.join(here, rel)
         if a.dtype == "bf16" and a.workload == "batch32" and a.batch == 32 and a.spec == "full" and os.path.exists(tf):
             with open(tf) as fh:
@@ -527,9 +530,42 @@ def main():
                            _rf("voc_conv", "mfma", round(MFMA_BF16_PEAK_TFLOPS / 6, 1) if voc_x3 else MFMA_F32_PEAK_TFLOPS),
                        "vocoder convs, HBM side (algorithmic bytes per launch)": _rf("voc_conv", "hbm", HBM_PEAK_GBS),
                        "vocoder conv_post+tanh+int16 (K13)": _rf("voc_post", "hbm", HBM_PEAK_GBS)}
+    # ---- the vocoder convs by stage: one entry per upsampler / MRF stack against the roof SURVEY 8(a) names for it
+    # (K11 stages 0-1 and K12: matrix; K11 stages 2-3: HBM), with the other side beside it
+    voc_peak = round(MFMA_BF16_PEAK_TFLOPS / 6, 1) if voc_x3 else MFMA_F32_PEAK_TFLOPS
+    voc_stages = {}
+    for name, bound in (("voc_pre", "hbm"), ("voc_up0", "mfma"), ("voc_up1", "mfma"), ("voc_up2", "hbm"), ("voc_up3", "hbm"),
+                        ("voc_mrf0", "mfma"), ("voc_mrf1", "mfma"), ("voc_mrf2", "mfma"), ("voc_mrf3", "mfma")):
+        v = prof.get(name)
+        if not v or not v["launches"] or v["ms"] <= 0:
+            continue
+        tf, gb = v["flops"] / 1e12 / (v["ms"] * 1e-3), v["bytes"] / 1e9 / (v["ms"] * 1e-3)
+        voc_stages[name] = {"bound": bound, "ms": round(v["ms"], 3), "launches": v["launches"], "TFLOP/s": round(tf, 2), "frac_mfma": round(tf / voc_peak, 4),
+                            "GB/s": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBS, 4), "flop_per_byte": round(v["flops"] / max(v["bytes"], 1.0), 1)}
+        if bound == "hbm" and name != "voc_pre":
+            other_rooflines[f"vocoder upsample stage {name[-1]} (K11, HBM-bound by SURVEY 8a)"] = {
+                "bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "launches": v["launches"]}
+    # ---- K5 GroupNorm: not on the synthesis path of this architecture (the survey lists it "as used"); one micro-measurement so that it has a number
+    if a.spec == "full":
+        gB, gC, gT, gG = a.batch, 512, GEN_FRAMES, 32
+        gx = torch.randn(gB, gC, gT, device=device)
+        gy, gg, gb_ = torch.empty_like(gx), torch.ones(gC, device=device), torch.zeros(gC, device=device)
+        st_ = torch.cuda.current_stream(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(25):
+            if it == 5:
+                e0.record(st_)
+            eng._check(eng.lib.vv_groupnorm(eng.ctx, gx.data_ptr(), gy.data_ptr(), gg.data_ptr(), gb_.data_ptr(), gB, gC, gT, gG, 1e-5, 0, st_.cuda_stream))
+        e1.record(st_)
+        torch.cuda.synchronize()
+        g_ms = e0.elapsed_time(e1) / 20
+        g_gbs = 8.0 * gx.numel() / 1e9 / (g_ms * 1e-3)
+        other_rooflines["groupnorm (K5; off the synthesis path, micro-measured)"] = {
+            "bound": "hbm", "achieved": round(g_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g_gbs / HBM_PEAK_GBS, 4), "launches": 20,
+            "shape": f"[{gB}, {gC}, {gT}] f32, {gG} groups; algorithmic bytes = one read + one write"}
     classes = {}
     for k, v in prof.items():
-        if v["launches"]:
+        if v["launches"] and not (k.startswith("voc_") and k not in ("voc_conv", "voc_post")):      # the stage classes repeat voc_conv: `vocoder_stages`
             classes[k] = {"ms": round(v["ms"], 2), "launches": v["launches"],
                           "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                           "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
@@ -556,7 +592,10 @@ def main():
                                 f"{len(batches)} length-bucketed batches {[b[0]['seq_len'].numel() for b in batches]} (row fill {fill:.3f}), ")
                                + f"{a.dtype} acoustic + fp32 vocoder, nfe_step={a.nfe} ({a.nfe - 1} Euler steps x 2 CFG branches)",
                    "spec": a.spec, "global_batch": world * a.batch, "parallelism": f"dp{world} (independent utterances, weight broadcast only)"},
-        "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes,
+        "roofline": roofline, "other_rooflines": other_rooflines, "kernel_classes": classes, "vocoder_stages": voc_stages,
+        "value_definition": "whole-job audio-seconds per wall second with the inputs resident in HBM when the timed region starts (the bench contract); "
+                            "SURVEY 8(d)'s host-to-host wording of the same metric is `pcie_inclusive` (rounds 1-3 reported that one as `value`: "
+                            "about 0.25 % lower)",
     }
     res["lanes"] = {"option": lanes_opt, "class_pass_ms": round(class_pass_ms, 2),
                     "what": "timed steps: the Euler steps run as two lanes (half batches, or the two CFG branches of a single item) on two HIP streams, "
@@ -568,6 +607,14 @@ def main():
     res["devices"] = devices
     if a.graph_steps:
         res["graph_steps"] = "all Euler steps + decode replayed from one captured hipGraph per batch shape (kernel-class timings from an eager pass)"
+    if world > 1:
+        # what the driver's scaling run needs to be read: every rank's own time and shard (weak scaling: 32 units per rank; for mixed256 the
+        # LPT shard sizes differ), the imbalance of the shard plan (max / mean of the ranks' frame rows and of their step times)
+        ms_all, rows_all = [p["ms_per_step"] for p in per_rank], [p["rows"] for p in per_rank]
+        res["per_rank"] = per_rank
+        res["shard_imbalance"] = {"rows_max_over_mean": round(max(rows_all) / (sum(rows_all) / world), 4),
+                                  "ms_max_over_mean": round(max(ms_all) / (sum(ms_all) / world), 4)}
+        res["env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
     if bcast_ms is not None:
         res["weight_pack_and_broadcast_ms"] = round(bcast_ms, 2)
         res["dist_backend"] = "nccl (RCCL)" if backend == "nccl" else backend + " (rehearsal: ranks may share a card)"

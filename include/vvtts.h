@@ -179,7 +179,12 @@ VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);
 #define VV_PROF_VOC_POST 6
 #define VV_PROF_MEL 7
 #define VV_PROF_TEXT 8
-#define VV_PROF_NCLASS 9
+/* the vocoder convs once more, by stage (each launch is counted in VV_PROF_VOC_CONV and in exactly one of these): conv_pre, the four
+ * transposed-conv upsamplers (K11), the four MRF stacks (K12) */
+#define VV_PROF_VOC_PRE 9
+#define VV_PROF_VOC_UP0 10      /* + stage, stages 0..3 */
+#define VV_PROF_VOC_MRF0 14     /* + stage, stages 0..3 */
+#define VV_PROF_NCLASS 18
 VV_API int vv_prof_enable(vv_ctx* ctx, int on);
 /* Synchronises, then fills per class: launches, total ms, algorithmic flops, algorithmic bytes. */
 VV_API int vv_prof_collect(vv_ctx* ctx, int64_t* launches, double* ms, double* flops, double* bytes);
@@ -284,7 +289,9 @@ typedef struct vv_conv_args {
     const void* W_x3;         /* optional: W split by vv_conv_split_weights; when given, the products run as exact 3-way bf16
                                  splits on the bf16 matrix pipe (six piece products, fp32 accumulate: fp32 fidelity, ~2.7x less
                                  matrix time) instead of v_mfma_f32_32x32x2_f32.  Same result class, not bit-identical. */
-    int32_t wg_rows;          /* x3 only: 0 = default (64-row workgroups of 4 waves), 128 = 128-row workgroups of 8 waves when rows_total > 64 */
+    int32_t wg_rows;          /* x3 only: 0 = default (64-row workgroups of 4 waves; the x2 up-samplers with 64 / 128 input channels take the
+                                 streaming kernel), 128 = 128-row workgroups of 8 waves when rows_total > 64, -1 = the generic kernel
+                                 also where the streaming one would be taken (its bit-identical twin: tests, A/B) */
 } vv_conv_args;
 VV_API int vv_conv1d(vv_ctx* ctx, const vv_conv_args* args, void* stream);
 /* W fp32 [Cin_pad][KW][rows_pad] -> out [ceil(Cin_pad / 16)][KW][3 pieces][2 octets][rows_pad][8] bf16 (w = h + m + l exactly, each piece the

@@ -130,6 +130,45 @@ def test_bf16_production_run_close_to_the_oracle_fixture(gold):
     assert wr <= 2.0 * BF16_MEASURED["wave"], wr
 
 
+def test_bf16_run_against_the_independent_bf16_yardstick(gold):
+    """what the bf16 path may cost is taken from an INDEPENDENT source, not from what the same kernels produced earlier:
+    tests/golden/fullsize_bf16_yardstick.* holds bench item 0 through the float64 oracle that rounds to bf16 exactly where the bf16
+    model stores bf16 (oracle/vv_oracle_bf16.py: GEMM / attention operands, activations between kernels; sums, norms, transcendentals and
+    the residual stream stay float64), for the first Euler steps of the production grid, next to the plain float64 run of the same
+    steps.  yardstick - float64 = the price of the FORMAT.  The HIP bf16 path is held to it at every kept step:
+      (a) its error against float64 is at most 1.25 x the yardstick's (it may not lose more than the format costs: fp32 accumulation,
+          approximate exp2 / rope angles and double roundings are inside the margin; a truncating conversion, a bf16 accumulator or a
+          missing fp32 residual would not be), and
+      (b) it sits CLOSER to the yardstick than float64 does (the two runs share the bulk of their rounding decisions)."""
+    from vietvoice_tts_amd.runtime import HipSynth
+    g = gold
+    with open(os.path.join(GOLD, "fullsize_bf16_yardstick.json")) as fh:
+        ym = json.load(fh)
+    ya = np.load(os.path.join(GOLD, "fullsize_bf16_yardstick.npz"))
+    assert ym["inputs"] == g["meta"]["inputs"] and ym["nfe_step"] == 32 and ym["item"] == 0
+    keep = ym["keep_steps"]
+    one = {k: v[0:1].contiguous().to(DEV) for k, v in g["d"].items() if torch.is_tensor(v)}
+    eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
+    pre = eng.preprocess(one["audio"], one["audio_len"], one["ids"], one["text_len"], one["seq_len"], g["N"], seq_len_host=[g["N"]])
+    x, st, bad = one["noise"].clone(), 0, []
+    rel = lambda got, ref: float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    for k in keep:
+        eng.transformer_steps(x, pre, st, k - st)
+        st = k
+        got = x[0].cpu().double()
+        src = ym["f64_states"][str(k)]                       # the float64 state: in this fixture, or the one fullsize_golden.npz already holds
+        f64 = torch.from_numpy(g["arr"][src.split(":")[1]] if ":" in src else ya[src]).double()
+        yard = torch.from_numpy(ya[f"yard_x{k}"]).double()
+        e_hip, e_yard, d_hy = rel(got, f64), ym["yardstick_vs_f64"][str(k)]["rmse_over_rms"], rel(got, yard)
+        print(f"\n[full bf16 vs yardstick] after step {k:2d}: HIP - f64 {e_hip:.3e} | yardstick - f64 {e_yard:.3e} | HIP - yardstick {d_hy:.3e}")
+        if not e_hip <= 1.25 * e_yard + 2e-7:
+            bad.append(("error vs float64 above the format's price", k, e_hip, e_yard))
+        if not d_hy <= 1.0 * e_yard + 2e-7:
+            bad.append(("further from the yardstick than float64 is", k, d_hy, e_yard))
+    eng.close()
+    assert not bad, bad
+
+
 def test_bf16_headline_batch_item0_production_run(gold):
     """configs[2] itself: the headline batch (B = 32, bench inputs, bf16 acoustic + fp32-fidelity vocoder) through
     `synthesize_batch` -- the call bench.py times -- with the production step count; item 0 of the batch against the oracle fixture

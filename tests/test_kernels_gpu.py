@@ -870,7 +870,7 @@ def _run_conv(eng, rt, gu, x, wp, bias, cout, T_out, KW, dil, up, resid=None, pr
     if x3:
         wb = _split_conv_weights(eng, rt, gu, dw)
         a.W_x3 = wb.data_ptr()
-        a.wg_rows = x3 if (isinstance(x3, int) and not isinstance(x3, bool)) else 0      # 128: the 8-wave workgroup form
+        a.wg_rows = x3 if (isinstance(x3, int) and not isinstance(x3, bool)) else 0      # 128: the 8-wave workgroup form; -1: never the streaming up-sampler
     gu.check(eng, eng.lib.vv_conv1d(eng.ctx, C.byref(a), gu.stream()))
     torch.cuda.synchronize()
     return out
@@ -1001,6 +1001,38 @@ def test_conv_transpose_polyphase(hip_tiny, u, cin, cout, T, x3):
     got = _run_conv(eng, rt, gu, x, wp, b, cout, T * u, 2, 1, u, pre_slope=0.1, x3=x3)
     assert ref.shape == got.shape
     assert gu.rel_err(got, ref) < TOL_F32
+
+
+@pytest.mark.parametrize("cin,cout,T,lens", [(64, 32, 1, None), (64, 32, 63, None), (64, 32, 64, None), (64, 32, 65, None), (64, 32, 1000, [1000, 333, 1]),
+                                             (128, 64, 40, None), (128, 64, 777, [777, 64, 500]), (128, 64, 4099, None)])
+def test_up2_stream_equals_generic_x3(hip_tiny, cin, cout, T, lens):
+    """Round 5: the x2 up-samplers (stages 2 and 3 of the vocoder: 128 -> 64 and 64 -> 32 channels) run a streaming kernel of their own
+    (up2_stream_x3_kernel: registers instead of an LDS window, waves as independent workers, paired 8-byte stores).  It keeps the generic
+    x3 kernel's contraction order, so it must be BIT-IDENTICAL to it (vv_conv_args.wg_rows = -1 forces the generic one), at every edge:
+    T = 1, column blocks of exactly / just over 64, ragged valid lengths -- and right against torch."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(cin + T)
+    B = 3 if lens else 2
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cin, cout, 4, generator=g) / math.sqrt(2 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    rows = cout * 2
+    wp = torch.zeros((cin, 2, (rows + 63) // 64 * 64))
+    wp[:, :, :rows] = w.reshape(cin, cout, 2, 2).permute(0, 2, 1, 3).reshape(cin, 2, rows)
+    stream = _run_conv(eng, rt, gu, x, wp, b, cout, T * 2, 2, 1, 2, pre_slope=0.1, lens=lens, x3=True)
+    generic = _run_conv(eng, rt, gu, x, wp, b, cout, T * 2, 2, 1, 2, pre_slope=0.1, lens=lens, x3=-1)
+    assert torch.equal(stream, generic)
+    for i in range(B):
+        L = lens[i] if lens else T
+        xi = x[i:i + 1].clone()
+        xi[:, :, L:] = 0
+        ref = F.conv_transpose1d(F.leaky_relu(xi, 0.1), w, b, stride=2, padding=1)
+        assert gu.rel_err(stream[i:i + 1], ref) < TOL_F32
+    # a destination with a guard band: nothing is written outside [B][Cout][2 T]
+    out0 = torch.full((B, cout, T * 2), 7.0)
+    again = _run_conv(eng, rt, gu, x, wp, b, cout, T * 2, 2, 1, 2, pre_slope=0.1, lens=lens, x3=True, out0=out0)
+    assert torch.equal(again, stream)
 
 
 def test_conv_post_pcm(hip_tiny):

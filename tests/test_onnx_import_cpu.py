@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from vietvoice_tts_amd import onnx_import as oi
+from tests import onnx_fixture_writer as ow
 from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
 
 
@@ -22,8 +23,8 @@ def test_wire_format_known_bytes():
     assert name == "w" and arr.dtype == np.float32 and arr.shape == (2, 3) and np.array_equal(arr.reshape(-1), vals)
     # varints: 300 = 0xAC 0x02; -1 as int64 = ten bytes
     assert oi._varint(memoryview(bytes([0xAC, 0x02])), 0) == (300, 2)
-    assert oi._enc_varint(300) == bytes([0xAC, 0x02]) and len(oi._enc_varint(-1)) == 10
-    assert oi._sint(oi._varint(memoryview(oi._enc_varint(-7)), 0)[0]) == -7
+    assert ow._enc_varint(300) == bytes([0xAC, 0x02]) and len(ow._enc_varint(-1)) == 10
+    assert oi._sint(oi._varint(memoryview(ow._enc_varint(-7)), 0)[0]) == -7
     with pytest.raises(ValueError):
         list(oi._fields(memoryview(bytes([0x0A, 0x7F, 1, 2]))))            # length runs past the buffer
 
@@ -35,17 +36,17 @@ def test_tensor_storage_round_trips(how, dtype):
     a = (rng.standard_normal((3, 4, 5)) * 50).astype(dtype)
     if np.issubdtype(dtype, np.signedinteger):
         a[0, 0, 0] = -12345
-    name, b = oi._tensor(memoryview(oi.encode_tensor("some.name", a, how)))
+    name, b = oi._tensor(memoryview(ow.encode_tensor("some.name", a, how)))
     assert name == "some.name" and b.dtype == a.dtype and np.array_equal(a, b)
-    s_name, s = oi._tensor(memoryview(oi.encode_tensor("scalar", np.array(3.5, np.float32), how if dtype == np.float32 else "raw")))
+    s_name, s = oi._tensor(memoryview(ow.encode_tensor("scalar", np.array(3.5, np.float32), how if dtype == np.float32 else "raw")))
     assert s.shape == () and float(s) == 3.5
 
 
 def test_bf16_and_external_data():
     a = np.random.default_rng(2).standard_normal(64).astype(np.float32)
-    _, b = oi._tensor(memoryview(oi.encode_tensor("x", a, "bf16")))
+    _, b = oi._tensor(memoryview(ow.encode_tensor("x", a, "bf16")))
     assert b.dtype == np.float32 and np.array_equal(b, torch.from_numpy(a).bfloat16().float().numpy())
-    ext = oi._vi(1, 64) + oi._vi(2, 1) + oi._ld(8, b"big") + oi._vi(14, 1)
+    ext = ow._vi(1, 64) + ow._vi(2, 1) + ow._ld(8, b"big") + ow._vi(14, 1)
     with pytest.raises(oi.UnsupportedGraph, match="external"):
         oi._tensor(memoryview(ext))
 
@@ -59,7 +60,7 @@ def test_model_round_trip_nodes_attrs_values():
     w = np.arange(12, dtype=np.float32).reshape(4, 3)                      # stored [in, out]
     inits = [("onnx::MatMul_7", w, "raw"), ("l.bias", np.ones(3, np.float32), "typed"), ("c.weight", np.zeros((2, 3, 7), np.float32), "raw"),
              ("c.bias", np.zeros(2, np.float32), "raw")]
-    data = oi.encode_model(nodes, inits, [oi.OnnxValue("x", 1, (1, "n", 4))], [oi.OnnxValue("z", 1, (1, 2, "n"))])
+    data = ow.encode_model(nodes, inits, [oi.OnnxValue("x", 1, (1, "n", 4))], [oi.OnnxValue("z", 1, (1, 2, "n"))])
     m = oi.parse_model(data)
     assert m.ir_version == 8 and m.opset == {"": 17} and m.producer == "pytorch" and m.graph_name == "main_graph"
     assert [n.op_type for n in m.nodes] == ["MatMul", "Add", "Conv"] and m.nodes[2].inputs == ["y", "c.weight", "c.bias"]
@@ -78,7 +79,7 @@ def test_model_round_trip_nodes_attrs_values():
 def test_import_recovers_spec_and_weights(preset, storage):
     spec = getattr(ModelSpec, preset)()
     w = make_synthetic_weights(spec, 77)
-    files = oi.export_archive_members(spec, w, storage)
+    files = ow.export_archive_members(spec, w, storage)
     models = {k: oi.parse_model(v) for k, v in files.items()}
     assert any(k.startswith("onnx::MatMul_") for k in models["transformer.onnx"].initializers)        # weights really are anonymous
     spec2, w2 = oi.import_graphs(models["preprocess.onnx"], models["transformer.onnx"], models["decode.onnx"], base=spec)
@@ -95,7 +96,7 @@ def test_import_recovers_spec_and_weights(preset, storage):
 
 def test_unsupported_graphs_are_named():
     spec = ModelSpec.tiny()
-    files = oi.export_archive_members(spec, make_synthetic_weights(spec, 1))
+    files = ow.export_archive_members(spec, make_synthetic_weights(spec, 1))
     pre, tr, dec = (oi.parse_model(files[k + ".onnx"]) for k in ("preprocess", "transformer", "decode"))
     dec_no_up = oi.OnnxModel(dec.ir_version, dec.opset, dec.producer, dec.graph_name, [n for n in dec.nodes if n.op_type != "ConvTranspose"],
                              dec.initializers, dec.inputs, dec.outputs)
@@ -121,7 +122,7 @@ def test_engine_loads_reference_layout_archive(tmp_path):
         for n in tar.getnames():
             if n != "model_spec.json":
                 members["pack/" + n if n.endswith("vocab.txt") else n] = tar.extractfile(n).read()       # nested path: matched by suffix
-    oi.write_onnx_archive(str(d2 / "model-bin.pt"), spec, make_synthetic_weights(spec, 9527), {k: v for k, v in members.items()})
+    ow.write_onnx_archive(str(d2 / "model-bin.pt"), spec, make_synthetic_weights(spec, 9527), {k: v for k, v in members.items()})
     seen = {}
 
     def factory(sp, weights, cfg):
@@ -136,3 +137,35 @@ def test_engine_loads_reference_layout_archive(tmp_path):
         outs.append(e.synthesize("Xin chào.")[0])
         e.cleanup()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_reader_on_hand_assembled_protobuf():
+    """The reader against bytes that do NOT come from tests/onnx_fixture_writer.py: a ModelProto assembled here byte by byte from the
+    public onnx.proto3 field numbers (ModelProto.graph = 7, GraphProto.node = 1 / name = 2 / initializer = 5 / input = 11 / output = 12,
+    NodeProto.input = 1 / output = 2 / name = 3 / op_type = 4 / attribute = 5, AttributeProto.name = 1 / i = 3 / ints = 8 / type = 20,
+    TensorProto.dims = 1 / data_type = 2 / float_data = 4 / int64_data = 7 / name = 8 / raw_data = 9; wire types 0 = varint,
+    2 = length-delimited, 5 = fixed32) -- so a field number that writer and reader both have wrong would show here."""
+    import struct
+    f32 = lambda *v: struct.pack("<%df" % len(v), *v)
+    # TensorProto "w": dims [2, 3], FLOAT (1), raw_data
+    t_w = bytes([0x08, 2, 0x08, 3, 0x10, 1, 0x42, 1]) + b"w" + bytes([0x4A, 24]) + f32(1, 2, 3, 4, 5, 6)
+    # TensorProto "b": dims packed [3] (field 1, wire type 2), FLOAT, float_data packed (field 4)
+    t_b = bytes([0x0A, 1, 3, 0x10, 1, 0x42, 1]) + b"b" + bytes([0x22, 12]) + f32(0.5, -1.5, 2.25)
+    # TensorProto "idx": dims [2], INT64 (7), int64_data packed (field 7): 300 = AC 02, -1 = ten bytes
+    t_i = bytes([0x08, 2, 0x10, 7, 0x42, 3]) + b"idx" + bytes([0x3A, 12, 0xAC, 0x02]) + bytes([0xFF] * 9 + [0x01])
+    # AttributeProto group = 4 (INT: type 2) and kernel_shape = [7] (INTS: type 7, unpacked field 8)
+    a_g = bytes([0x0A, 5]) + b"group" + bytes([0x18, 4, 0xA0, 0x01, 2])
+    a_k = bytes([0x0A, 12]) + b"kernel_shape" + bytes([0x40, 7, 0xA0, 0x01, 7])
+    node = (bytes([0x0A, 1]) + b"x" + bytes([0x0A, 1]) + b"w" + bytes([0x0A, 1]) + b"b" + bytes([0x12, 1]) + b"y" + bytes([0x1A, 5]) + b"/c/Cv"
+            + bytes([0x22, 4]) + b"Conv" + bytes([0x2A, len(a_g)]) + a_g + bytes([0x2A, len(a_k)]) + a_k)
+    graph = (bytes([0x0A, len(node)]) + node + bytes([0x12, 1]) + b"g" + bytes([0x2A, len(t_w)]) + t_w + bytes([0x2A, len(t_b)]) + t_b
+             + bytes([0x2A, len(t_i)]) + t_i)
+    assert 128 <= len(graph) < 16384
+    model = bytes([0x08, 8]) + bytes([0x3A, 0x80 | (len(graph) & 0x7F), len(graph) >> 7]) + graph     # ir_version = 8; graph, two-byte length varint
+    m = oi.parse_model(model)
+    assert [n.op_type for n in m.nodes] == ["Conv"] and m.nodes[0].name == "/c/Cv"
+    assert m.nodes[0].inputs == ["x", "w", "b"] and m.nodes[0].outputs == ["y"]
+    assert m.nodes[0].attrs["group"] == 4 and list(m.nodes[0].attrs["kernel_shape"]) == [7]
+    assert m.initializers["w"].dtype == np.float32 and m.initializers["w"].tolist() == [[1, 2, 3], [4, 5, 6]]
+    assert m.initializers["b"].tolist() == [0.5, -1.5, 2.25]
+    assert m.initializers["idx"].dtype == np.int64 and m.initializers["idx"].tolist() == [300, -1]

@@ -84,3 +84,28 @@ def test_rope_text_and_time_tables(spec):
         # and the oracle's whole time MLP consumes exactly that table
         h = torch.nn.functional.silu(torch.nn.functional.linear(ref, w["time.mlp1.weight"], w["time.mlp1.bias"]))
         assert torch.allclose(orc.time_embed(step), torch.nn.functional.linear(h, w["time.mlp2.weight"], w["time.mlp2.bias"]), atol=1e-6)
+
+
+def test_bf16_yardstick_is_the_float64_oracle_plus_roundings(monkeypatch):
+    """oracle/vv_oracle_bf16.py restates the model's data flow with bf16 roundings at the bf16 model's storage points.  With the
+    rounding function replaced by the identity it must BE the float64 oracle (same graph, same order of additions); with it, the
+    result moves by a bf16-class amount and not more."""
+    from oracle import vv_oracle_bf16 as yb
+    from oracle.vv_oracle import Oracle
+    from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
+    spec = ModelSpec.tiny()
+    w = make_synthetic_weights(spec, 9527)
+    g = torch.Generator().manual_seed(3)
+    S, T, gen = 256 * 14, 20, 10
+    audio = (torch.randn(S, generator=g) * 3000).to(torch.int16)
+    ids = torch.randint(0, spec.vocab_size, (T,), generator=g, dtype=torch.int32)
+    N = S // spec.hop_length + 1 + gen
+    noise = torch.randn(N, spec.n_mel, generator=g)
+    with torch.no_grad():
+        x64, _ = Oracle(spec, w, nfe_step=6, dtype=torch.float64).synthesize(audio, ids, N, noise)
+        xb, _ = yb.Bf16Oracle(spec, w, nfe_step=6).synthesize(audio, ids, N, noise)
+        monkeypatch.setattr(yb, "rb", lambda t: t)
+        xi, _ = yb.Bf16Oracle(spec, w, nfe_step=6).synthesize(audio, ids, N, noise)
+    rel = lambda a, b: float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    assert rel(xi, x64) < 1e-12, rel(xi, x64)
+    assert 1e-5 < rel(xb, x64) < 3e-2, rel(xb, x64)

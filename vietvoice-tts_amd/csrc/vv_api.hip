@@ -17,7 +17,7 @@ std::string g_create_error;
 
 struct Bound { const void* p; uint64_t bytes; };
 
-struct ProfRec { hipEvent_t a, b; int cls; };
+struct ProfRec { hipEvent_t a, b; int cls, sub; };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pad_to(int v, int a) { return (v + a - 1) / a * a; }
@@ -116,9 +116,10 @@ namespace {
 
 struct Prof {
     vv_ctx* c; int idx = -1; hipStream_t st;
-    Prof(vv_ctx* c_, int cls, double flops, double bytes, hipStream_t st_) : c(c_), st(st_) {
+    Prof(vv_ctx* c_, int cls, double flops, double bytes, hipStream_t st_, int sub = -1) : c(c_), st(st_) {
         if (!c->prof) return;
-        ProfRec r; r.cls = cls;
+        ProfRec r; r.cls = cls; r.sub = sub;
+        if (sub >= 0) { c->p_launch[sub]++; c->p_flops[sub] += flops; c->p_bytes[sub] += bytes; }
         auto get = [&]() { hipEvent_t e; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else hipEventCreate(&e); return e; };
         r.a = get(); r.b = get();
         hipEventRecord(r.a, st);
@@ -846,7 +847,7 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
     }
     const bool x3 = c->voc_x3 == 1 || (c->voc_x3 < 0 && c->dt == VV_DTYPE_BF16);
     auto conv = [&](const float* in, const std::string& name, float* out, const float* resid, int Cin, int Cout, int T_in, int T_out, int KW,
-                    int dil, int up, float pre_slope, float scale, int accumulate, const int* len_in) -> int {
+                    int dil, int up, float pre_slope, float scale, int accumulate, const int* len_in, int stage_cls) -> int {
         vv_conv_args a{};
         a.in = in; a.W = c->Wf(name + ".weight"); a.bias = c->Wf(name + ".bias"); a.out = out; a.resid = resid;
         if (x3) {
@@ -859,25 +860,27 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
         a.pre_slope = pre_slope; a.out_scale = scale; a.len_in = len_in;
         const double taps = up > 0 ? 2.0 : (double)KW;
         Prof p(c, VV_PROF_VOC_CONV, 2.0 * B * (double)T_out * Cout * Cin * taps,
-               4.0 * B * ((double)Cin * T_in + (double)Cout * T_out * (1 + (resid ? 1 : 0) + (accumulate ? 1 : 0))), st);
+               4.0 * B * ((double)Cin * T_in + (double)Cout * T_out * (1 + (resid ? 1 : 0) + (accumulate ? 1 : 0))), st, stage_cls);
         const char* m = "";
         int r = vvk_conv(&a, st, &m);
         if (r) return c->fail(r, "%s (%s)", m, name.c_str());
         return 0;
     };
-    if (int r = conv(v0, "voc.pre", buf[0], nullptr, M, Cs[0], Ts[0], Ts[0], g.voc_pre_k, 1, 0, 1.0f, 1.0f, 0, lens)) return r;
+    if (int r = conv(v0, "voc.pre", buf[0], nullptr, M, Cs[0], Ts[0], Ts[0], g.voc_pre_k, 1, 0, 1.0f, 1.0f, 0, lens, VV_PROF_VOC_PRE)) return r;
     float* cur = buf[0];
     float* up_out = buf[1];
     for (int s = 0; s < nu; ++s) {
         const int C = Cs[s + 1], T = Ts[s + 1];
         const int* len_s = lens + (size_t)(s + 1) * B;
-        if (int r = conv(cur, "voc.up." + std::to_string(s), up_out, nullptr, Cs[s], C, Ts[s], T, 2, 1, g.voc_up_rates[s], g.voc_lrelu, 1.0f, 0, lens + (size_t)s * B)) return r;
+        if (int r = conv(cur, "voc.up." + std::to_string(s), up_out, nullptr, Cs[s], C, Ts[s], T, 2, 1, g.voc_up_rates[s], g.voc_lrelu, 1.0f, 0, lens + (size_t)s * B,
+                         s < 4 ? VV_PROF_VOC_UP0 + s : -1)) return r;
         // MRF: acc = (1/n_res) * sum_a resblock_a(up_out)
         float* acc = cur;                                   // previous stage input is dead now
         float* t1 = (up_out == buf[1]) ? buf[2] : buf[1];
         float* ya = buf[3];
         float* yb = buf[4];
         const float inv = 1.0f / (float)g.voc_n_res;
+        const int mrf_cls = s < 4 ? VV_PROF_VOC_MRF0 + s : -1;
         for (int a = 0; a < g.voc_n_res; ++a) {
             const float* y = up_out;
             for (int b = 0; b < g.voc_n_dil; ++b) {
@@ -892,12 +895,12 @@ static int decode_impl(vv_ctx* c, int B, int N, const float* x, const int32_t* r
                     m.y = y; m.W1 = c->Wf(q + ".conv1.weight"); m.b1 = c->Wf(q + ".conv1.bias"); m.W2 = c->Wf(q + ".conv2.weight"); m.b2 = c->Wf(q + ".conv2.bias");
                     m.out = dst; m.B = B; m.C = C; m.T = T; m.KW = kw; m.dil = dil; m.rows_pad = 64; m.accumulate = last && a > 0;
                     m.slope = g.voc_lrelu; m.out_scale = last ? inv : 1.0f; m.len_in = len_s;
-                    Prof p(c, VV_PROF_VOC_CONV, 2.0 * 2.0 * B * (double)T * C * C * kw, 4.0 * B * (double)C * T * (2 + (m.accumulate ? 1 : 0)), st);
+                    Prof p(c, VV_PROF_VOC_CONV, 2.0 * 2.0 * B * (double)T * C * C * kw, 4.0 * B * (double)C * T * (2 + (m.accumulate ? 1 : 0)), st, mrf_cls);
                     const char* em = "";
                     if (int r = vvk_mrf_pair(&m, st, &em)) return c->fail(r, "%s (%s)", em, q.c_str());
                 } else {
-                    if (int r = conv(y, q + ".conv1", t1, nullptr, C, C, T, T, kw, dil, 0, g.voc_lrelu, 1.0f, 0, len_s)) return r;
-                    if (int r = conv(t1, q + ".conv2", dst, y, C, C, T, T, kw, 1, 0, g.voc_lrelu, last ? inv : 1.0f, last && a > 0, len_s)) return r;
+                    if (int r = conv(y, q + ".conv1", t1, nullptr, C, C, T, T, kw, dil, 0, g.voc_lrelu, 1.0f, 0, len_s, mrf_cls)) return r;
+                    if (int r = conv(t1, q + ".conv2", dst, y, C, C, T, T, kw, 1, 0, g.voc_lrelu, last ? inv : 1.0f, last && a > 0, len_s, mrf_cls)) return r;
                 }
                 y = dst;
             }
@@ -982,7 +985,7 @@ int vv_prof_collect(vv_ctx* c, int64_t* launches, double* ms, double* flops, dou
     HIPCHK(c, hipDeviceSynchronize());
     for (auto& r : c->recs) {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) c->p_ms[r.cls] += t;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { c->p_ms[r.cls] += t; if (r.sub >= 0) c->p_ms[r.sub] += t; }
         c->pool.push_back(r.a); c->pool.push_back(r.b);
     }
     c->recs.clear();

@@ -291,6 +291,140 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, O
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// K11x, the x2 up-samplers (stages 2 and 3: 128 -> 64 and 64 -> 32 channels, kernel 4, stride 2) as a STREAM.  SURVEY 8(a) puts these
+// two on the HBM roof (arithmetic intensity 64 / 32 flop per byte against a ridge of ~52 for the six-term form), and the generic
+// kernel above reached 0.23 / 0.35 of it: a workgroup there has ONE 16-channel window (16.5 KB) in flight, behind a barrier, and its
+// epilogue stores every other float (the two phases of a channel are different accumulator registers).  Here:
+//   * no LDS and no barrier on the data path: the polyphase form has only two taps (input times q and q - 1), so a lane loads the 8
+//     channels of its k-half at its own column directly into registers (256-byte runs per load instruction, as before), splits them
+//     in registers (LeakyReLU fused) and uses them as the MFMA B fragment; the tap at q - 1 is loaded again (the same lines, from L1);
+//   * a wave is an independent worker over (item, 64-column block) units of its workgroup's 64-row tile; the next chunk's loads are
+//     issued before a chunk's MFMAs and the NEXT UNIT's first chunk before the epilogue, so 2 x 8 KB of loads per wave -- 128 KB per
+//     CU at 8 waves -- are in flight all the time, also while a unit's stores drain;
+//   * all weights of the row tile (49 / 98 KB split) are loaded into LDS once per workgroup (persistent: 256 workgroups walk all units);
+//   * the two phases of an output channel sit in adjacent accumulator registers of one lane (rows co * 2 + phase): stored as ONE
+//     8-byte store, a wave's store instruction writes 512 contiguous bytes.
+// The contraction order (chunk, tap, the six piece products smallest first) is the generic kernel's: results are BIT-IDENTICAL to it
+// (tests/test_kernels_gpu.py::test_up2_stream_equals_generic_x3).
+template <int NCH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up2_stream_x3_kernel(
+    const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias, float* __restrict__ out, int rows_pad, int T_in,
+    int T_out, int Cout, float pre_slope, float out_scale, const int* __restrict__ len_in, int n_qb, int n_rt, int n_units) {
+    constexpr int Cin = NCH * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* wsl = (u32x4*)smem;                         // [NCH][2 taps][3 pieces][2 octets][64 rows]
+    const int id = blockIdx.x;
+    const int rt = (id >> 3) % n_rt;                   // workgroups 8 apart share an XCD: the row tiles of one window walk it together
+    const int slot = ((id >> 3) / n_rt) * 8 + (id & 7);
+    const int n_slots = gridDim.x / n_rt;
+    const int r0 = rt * 64;
+    for (int i = threadIdx.x; i < NCH * 768; i += 512) wsl[i] = Wb[(size_t)(i >> 6) * rows_pad + r0 + (i & 63)];
+    __syncthreads();                                   // the only barrier: from here on every wave runs by itself
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int stride = n_slots * 8;
+    int u = slot * 8 + wave;
+    if (u >= n_units) return;
+
+    typedef float xbuf_t[2][2][8];                     // [time tile][tap][channel of the k-half]
+    xbuf_t xa, xb;
+    auto issue = [&](xbuf_t& x, int unit, int ch) {
+        const int b = unit / n_qb, q0 = (unit - b * n_qb) * 64;
+        const int lin = len_in ? min(len_in[b], T_in) : T_in;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)b * Cin * T_in), 0, Cin * T_in * 4, 0x00020000);
+        const int c0 = ch * 16 + 8 * h;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tap = 0; tap < 2; ++tap) {
+                const int time = q0 + ti * 32 + r32 - tap;
+                // one vector offset per (time tile, tap); the channel step j * T_in goes into the SCALAR offset, which the range check
+                // ignores: an invalid column keeps its offset past num_records for all 8 loads and reads zero
+                const unsigned off = (time >= 0 && time < lin) ? (unsigned)(c0 * T_in + time) * 4u : 0x80000000u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[ti][tap][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, j * T_in * 4, 0));
+            }
+    };
+    f32x16 acc[2][2];
+    auto compute = [&](const xbuf_t& x, int ch) {
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw) {
+            bf16x8 a[2][3], xf[2][3];
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) a[ri][pc] = __builtin_bit_cast(bf16x8, wsl[(((ch * 2 + kw) * 3 + pc) * 2 + h) * 64 + ri * 32 + r32]);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                u32x4 wh, wm, wl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hh, mm, ll;
+                    lrelu_split3_pair(x[ti][kw][2 * j], x[ti][kw][2 * j + 1], pre_slope, hh, mm, ll);
+                    wh[j] = hh; wm[j] = mm; wl[j] = ll;
+                }
+                xf[ti][0] = __builtin_bit_cast(bf16x8, wh); xf[ti][1] = __builtin_bit_cast(bf16x8, wm); xf[ti][2] = __builtin_bit_cast(bf16x8, wl);
+            }
+#define VV_UP2_TERM(pa, pb)                                                                                                 \
+    _Pragma("unroll") for (int ri = 0; ri < 2; ++ri) _Pragma("unroll") for (int ti = 0; ti < 2; ++ti)                         \
+        acc[ri][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ri][pa], xf[ti][pb], acc[ri][ti], 0, 0, 0)
+            VV_UP2_TERM(0, 2); VV_UP2_TERM(2, 0); VV_UP2_TERM(1, 1); VV_UP2_TERM(0, 1); VV_UP2_TERM(1, 0); VV_UP2_TERM(0, 0);
+#undef VV_UP2_TERM
+        }
+    };
+
+    issue(xa, u, 0);
+    while (true) {
+        const int un = u + stride;                     // wave-uniform
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ri][ti][r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch += 2) {
+            issue(xb, u, ch + 1);
+            compute(xa, ch);
+            if (ch + 2 < NCH) issue(xa, u, ch + 2);
+            else if (un < n_units) issue(xa, un, 0);   // the next unit's first window is in flight while this unit's stores drain
+            compute(xb, ch + 1);
+        }
+        // ---- epilogue: D[row_local = (r & 3) + 8 (r >> 2) + 4 h][column r32]; rows (2 co, 2 co + 1) = the two phases of channel co,
+        // output times 2 q - 1 and 2 q: registers (r, r + 1), r even, are adjacent samples of one channel
+        const int b = u / n_qb, q0 = (u - b * n_qb) * 64;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)b * Cout * T_out), 0, Cout * T_out * 4, 0x00020000);
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int q = q0 + ti * 32 + r32;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int co = (r0 + ri * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) >> 1;
+                    const float bv = bias[co];
+                    float v0 = acc[ri][ti][r] + bv, v1 = acc[ri][ti][r + 1] + bv;
+                    v0 *= out_scale; v1 *= out_scale;
+                    const unsigned e = (unsigned)(co * T_out + 2 * q - 1);
+                    if (q >= 1 && q < T_in) {
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        const u32x2 pv = {__float_as_uint(v0), __float_as_uint(v1)};
+                        __builtin_amdgcn_raw_buffer_store_b64(pv, rs_out, (int)(e * 4u), 0, 0);
+                    } else if (q == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rs_out, (int)((e + 1u) * 4u), 0, 0);
+                    } else if (q == T_in) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rs_out, (int)(e * 4u), 0, 0);
+                    }
+                }
+            }
+        if (un >= n_units) break;
+        u = un;
+    }
+}
+
 struct X3Setup {                                       // dynamic LDS above 64 KiB needs the attribute once per kernel and device
     std::mutex mu;
     std::atomic<unsigned long long> done{0};
@@ -327,8 +461,31 @@ hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
                                                               n_tt, n_rt, n_tt * a->B);
     return hipGetLastError();
 }
+template <int NCH>
+hipError_t launch_up2_stream(const vv_conv_args* a, hipStream_t st) {
+    static X3Setup setup;
+    auto kern = up2_stream_x3_kernel<NCH>;
+    const int lds = NCH * 768 * 16;
+    if (hipError_t he = setup.ensure((const void*)kern, lds); he != hipSuccess) return he;
+    const int n_qb = (a->T_in + 1 + 63) / 64, n_rt = a->rows_total / 64;
+    const long long units = (long long)n_qb * a->B;
+    if (units > 0x7fffffffLL) return hipErrorInvalidValue;
+    int grid = 256 / (8 * n_rt) * (8 * n_rt);          // one persistent workgroup per CU, a whole number of (XCD group, row tile) sets
+    while (grid > 8 * n_rt && (long long)(grid / n_rt - 8) * 8 >= units) grid -= 8 * n_rt;      // short inputs: no idle workgroups loading weights
+    kern<<<dim3((unsigned)grid), 512, lds, st>>>(a->in, (const u32x4*)a->W_x3, a->bias, a->out, a->rows_pad, a->T_in, a->T_out, a->Cout, a->pre_slope,
+                                                 a->out_scale, a->len_in, n_qb, n_rt, (int)units);
+    return hipGetLastError();
+}
+
+// the streaming form serves the x2 up-samplers (no residual, no accumulate) with 64 or 128 input channels
+static bool up2_stream_fits(const vv_conv_args* a) {
+    return a->transposed && a->up == 2 && a->KW == 2 && !a->resid && !a->accumulate && (a->Cin == 64 || a->Cin == 128) && a->rows_total % 64 == 0 &&
+           a->rows_total >= 64 && a->rows_total <= 128 && a->wg_rows != -1;
+}
+
 template <int KW, bool TR>
 hipError_t launch_x3(const vv_conv_args* a, hipStream_t st) {
+    if (TR && up2_stream_fits(a)) return a->Cin == 64 ? launch_up2_stream<4>(a, st) : launch_up2_stream<8>(a, st);
     if (a->rows_total <= 32) return launch_x3_t<KW, TR, 1, 2, 4, 3>(a, st);      // narrow stage: no zero-padded MFMA rows; 42 KiB of LDS: 3 workgroups per CU
     // 64-row workgroups of 4 waves by default: 128-row workgroups of 8 waves (the window split once for twice the rows) are 1-3 %
     // faster per launch on the k = 3 shapes but 1.2 % slower in the decode (one resident workgroup per CU: nothing overlaps its epilogue)

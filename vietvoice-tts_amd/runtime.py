@@ -22,7 +22,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VVTTS_LIB") or os.path.join(_HERE, "libvvtts_hip.so")   # VVTTS_LIB: A/B builds in tools/
 
 VV_F32, VV_BF16 = 0, 1
-PROF_CLASSES = ["gemm", "attention", "norm", "posconv", "elementwise", "voc_conv", "voc_post", "mel", "text"]
+PROF_CLASSES = ["gemm", "attention", "norm", "posconv", "elementwise", "voc_conv", "voc_post", "mel", "text",
+                "voc_pre", "voc_up0", "voc_up1", "voc_up2", "voc_up3", "voc_mrf0", "voc_mrf1", "voc_mrf2", "voc_mrf3"]   # voc_conv once more, by stage
 
 
 class HipUnavailable(RuntimeError):
