@@ -329,6 +329,7 @@ def test_engine_from_reference_layout_onnx_archive(tmp_path):
     PCM the synthetic pack with the same weights produces.  (The real archive's naming is unpinned: see onnx_import.py.)"""
     import tarfile
     from vietvoice_tts_amd import onnx_import as oi
+    from tests import onnx_fixture_writer as ow
     from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
     a = _engine(tmp_path)
     wa, _ = a.synthesize("Xin chào các bạn.")

@@ -64,15 +64,15 @@ def main():
             nb = int(eng.lib.vv_conv_split_bytes(cin_pad, kw, rows_pad))
             wb = torch.zeros(nb // 2, dtype=torch.int16, device=DEV)
             assert eng.lib.vv_conv_split_weights(eng.ctx, wp.data_ptr(), cin_pad, kw, rows_pad, wb.data_ptr(), st) == 0
-            for mode in ((0, 1, 2) if en == engs[0][0] else (1,)):         # 0 f32 MFMA, 1 x3 (auto workgroup), 2 x3 with 128-row workgroups
+            for mode in ((0, 1, 2, 3) if en == engs[0][0] else (1,)):      # 0 f32 MFMA, 1 x3 (auto: the x2 up-samplers stream), 2 x3 with 128-row workgroups, 3 x3 generic kernel forced
                 a = rt.vv_conv_args()
                 a.in_, a.W, a.bias, a.out = x.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr()
                 a.B, a.Cin, a.Cout, a.T_in, a.T_out, a.KW, a.dil = B, cin, cout, T, T_out, kw, dil
                 a.transposed, a.up, a.rows_total, a.rows_pad = (1 if up else 0), up, rows, rows_pad
                 a.pre_slope, a.out_scale = 0.1, 1.0
                 a.W_x3 = wb.data_ptr() if mode else None
-                a.wg_rows = (0, 0, 128)[mode]
-                if mode == 2 and rows <= 64:
+                a.wg_rows = (0, 0, 128, -1)[mode]
+                if (mode == 2 and rows <= 64) or (mode == 3 and up != 2):
                     continue
                 assert eng.lib.vv_conv1d(eng.ctx, C.byref(a), st) == 0, eng.lib.vv_last_error(eng.ctx)
                 torch.cuda.synchronize()
@@ -85,9 +85,9 @@ def main():
                 ms = e0.elapsed_time(e1) / iters
                 key = (en, mode)
                 tot[key] = tot.get(key, 0.0) + ms
-                line += f" | {en if len(engs) > 1 else ''} {('f32', 'x3', 'x3/128')[mode]} {ms:6.3f} {flops / ms / 1e9:5.1f}"
+                line += f" | {en if len(engs) > 1 else ''} {('f32', 'x3', 'x3/128', 'x3-generic')[mode]} {ms:6.3f} {flops / ms / 1e9:5.1f}"
         print(line, flush=True)
-    print("sum of shapes (one launch each):", {f"{k[0]}/{('f32', 'x3', 'x3-128rows (>64-row shapes only)')[k[1]]}": round(v, 3) for k, v in tot.items()})
+    print("sum of shapes (one launch each):", {f"{k[0]}/{('f32', 'x3', 'x3-128rows (>64-row shapes only)', 'x3-generic (x2 up-samplers only)')[k[1]]}": round(v, 3) for k, v in tot.items()})
 
 
 main()

@@ -241,9 +241,9 @@ class HipSynth:
         self.rope = tuple(t.to(self.device) for t in (cq, sq, ck, sk))
         # the tables this engine hands to the transformer stage are the standard ones of spec.rope_theta: the bf16 model may compute the
         # angles in the QKV epilogue instead of reading them (vv_set_rope_theta; the fp32 model reads the tables either way)
-        self._check(self.lib.vv_set_rope_theta(self.ctx, float(spec.rope_theta)))
-        self.nfe_step = None
         self.grid_generation = 0         # bumped by whatever a captured Euler-step graph has baked in (time grid, rope mode, options)
+        self.set_rope_theta(float(spec.rope_theta))
+        self.nfe_step = None
         self.set_nfe(nfe_step)
 
     # ------------------------------------------------------------------ plumbing
@@ -429,7 +429,7 @@ class HipSynth:
         0: the tables are read (vv_set_rope_theta)."""
         self._check(self.lib.vv_set_rope_theta(self.ctx, float(theta)))
         self._rope_theta = float(theta)
-        self.grid_generation = getattr(self, "grid_generation", 0) + 1
+        self.grid_generation += 1
 
     @contextlib.contextmanager
     def reading_rope_tables(self):
@@ -437,7 +437,7 @@ class HipSynth:
         is fed non-standard tables).  Holds the engine lock, so no other call and no graph replay sees the switched mode; the
         previous mode is restored on exit (captured graphs stay valid: none can run in between)."""
         with self._lock:
-            prev = getattr(self, "_rope_theta", 0.0)
+            prev = self._rope_theta
             self._check(self.lib.vv_set_rope_theta(self.ctx, 0.0))
             try:
                 yield
