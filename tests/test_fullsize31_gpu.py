@@ -136,10 +136,14 @@ def test_bf16_run_against_the_independent_bf16_yardstick(gold):
     model stores bf16 (oracle/vv_oracle_bf16.py: GEMM / attention operands, activations between kernels; sums, norms, transcendentals and
     the residual stream stay float64), for the first Euler steps of the production grid, next to the plain float64 run of the same
     steps.  yardstick - float64 = the price of the FORMAT.  The HIP bf16 path is held to it at every kept step:
-      (a) its error against float64 is at most 1.25 x the yardstick's (it may not lose more than the format costs: fp32 accumulation,
-          approximate exp2 / rope angles and double roundings are inside the margin; a truncating conversion, a bf16 accumulator or a
-          missing fp32 residual would not be), and
-      (b) it sits CLOSER to the yardstick than float64 does (the two runs share the bulk of their rounding decisions)."""
+      (a) its error against float64 is the yardstick's within +-10 % (measured round 5: 1.834e-5 / 2.479e-4 / 9.016e-4 / 1.864e-3
+          against 1.832e-5 / 2.485e-4 / 9.046e-4 / 1.871e-3 after steps 1 / 4 / 8 / 12: the same to three digits -- it loses what the
+          format costs and nothing else: fp32 accumulation, approximate exp2 / rope angles and double roundings are inside the margin;
+          a truncating conversion, a bf16 accumulator or a missing fp32 residual would not be; and an error far BELOW the format's
+          price would mean the run is not the bf16 model at all), and
+      (b) it is no further from the yardstick than 1.2 x the format's price (measured 0.69-0.94 x: two realisations of the same
+          rounding noise decorrelate as the perturbation flips roundings downstream, so their distance approaches sqrt(2) x only for
+          a path with a DIFFERENT error mechanism; a systematic deviation shows here first)."""
     from vietvoice_tts_amd.runtime import HipSynth
     g = gold
     with open(os.path.join(GOLD, "fullsize_bf16_yardstick.json")) as fh:
@@ -161,10 +165,10 @@ def test_bf16_run_against_the_independent_bf16_yardstick(gold):
         yard = torch.from_numpy(ya[f"yard_x{k}"]).double()
         e_hip, e_yard, d_hy = rel(got, f64), ym["yardstick_vs_f64"][str(k)]["rmse_over_rms"], rel(got, yard)
         print(f"\n[full bf16 vs yardstick] after step {k:2d}: HIP - f64 {e_hip:.3e} | yardstick - f64 {e_yard:.3e} | HIP - yardstick {d_hy:.3e}")
-        if not e_hip <= 1.25 * e_yard + 2e-7:
-            bad.append(("error vs float64 above the format's price", k, e_hip, e_yard))
-        if not d_hy <= 1.0 * e_yard + 2e-7:
-            bad.append(("further from the yardstick than float64 is", k, d_hy, e_yard))
+        if not 0.9 * e_yard - 2e-7 <= e_hip <= 1.1 * e_yard + 2e-7:
+            bad.append(("error vs float64 is not the format's price", k, e_hip, e_yard))
+        if not d_hy <= 1.2 * e_yard + 2e-7:
+            bad.append(("too far from the yardstick", k, d_hy, e_yard))
     eng.close()
     assert not bad, bad
 

@@ -19,7 +19,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob("$OUT/cpmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(fn)):
         kn = row["Kernel_Name"]
-        if "conv_x3_kernel" in kn or "conv_mfma_kernel" in kn:
+        if "conv_x3_kernel" in kn or "conv_mfma_kernel" in kn or "up2_stream" in kn:
             key = kn.split("(")[0][-60:] + " grid=" + row.get("Grid_Size", "?")
             per[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("$OUT/conv_pmc.txt", "w") as f:

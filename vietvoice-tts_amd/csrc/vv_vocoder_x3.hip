@@ -292,22 +292,33 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(OCC, O
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// K11x, the x2 up-samplers (stages 2 and 3: 128 -> 64 and 64 -> 32 channels, kernel 4, stride 2) as a STREAM.  SURVEY 8(a) puts these
-// two on the HBM roof (arithmetic intensity 64 / 32 flop per byte against a ridge of ~52 for the six-term form), and the generic
-// kernel above reached 0.23 / 0.35 of it: a workgroup there has ONE 16-channel window (16.5 KB) in flight, behind a barrier, and its
-// epilogue stores every other float (the two phases of a channel are different accumulator registers).  Here:
+// K11x, the x2 up-samplers (stages 2 and 3: 128 -> 64 and 64 -> 32 channels, kernel 4, stride 2) as a STREAM (round 5).  SURVEY 8(a)
+// puts these two on the HBM roof (arithmetic intensity 64 / 32 flop per byte against a ridge of ~52 for the six-term form); the generic
+// kernel above keeps ONE 16-channel window (16.5 KB) per workgroup in flight, behind a barrier, and its epilogue stores every other
+// float (the two phases of a channel are different accumulator registers).  Here:
 //   * no LDS and no barrier on the data path: the polyphase form has only two taps (input times q and q - 1), so a lane loads the 8
-//     channels of its k-half at its own column directly into registers (256-byte runs per load instruction, as before), splits them
-//     in registers (LeakyReLU fused) and uses them as the MFMA B fragment; the tap at q - 1 is loaded again (the same lines, from L1);
+//     channels of its k-half at its own column directly into registers (the channel step rides in the SCALAR offset of the buffer
+//     load: one vector offset per (column block, tap)), splits them in registers (LeakyReLU fused) and uses them as the MFMA B
+//     fragment; the tap at q - 1 is loaded again (the same lines);
 //   * a wave is an independent worker over (item, 64-column block) units of its workgroup's 64-row tile; the next chunk's loads are
-//     issued before a chunk's MFMAs and the NEXT UNIT's first chunk before the epilogue, so 2 x 8 KB of loads per wave -- 128 KB per
-//     CU at 8 waves -- are in flight all the time, also while a unit's stores drain;
+//     issued before a chunk's MFMAs and the NEXT UNIT's first chunk before the epilogue (loads fly while a unit's stores drain);
 //   * all weights of the row tile (49 / 98 KB split) are loaded into LDS once per workgroup (persistent: 256 workgroups walk all units);
 //   * the two phases of an output channel sit in adjacent accumulator registers of one lane (rows co * 2 + phase): stored as ONE
-//     8-byte store, a wave's store instruction writes 512 contiguous bytes.
+//     8-byte store, a wave's store instruction writes two runs of 256 contiguous bytes.
 // The contraction order (chunk, tap, the six piece products smallest first) is the generic kernel's: results are BIT-IDENTICAL to it
 // (tests/test_kernels_gpu.py::test_up2_stream_equals_generic_x3).
-template <int NCH>
+// Measured (profiles/r05/vocoder_notes.md, B = 32, alternated with the generic kernel in one process): stage 3 0.62-0.64 ms against
+// 0.68-0.70 (3.4-3.5 TB/s of algorithmic bytes = 0.43-0.44 of the HBM peak), stage 2 0.96 against 1.00-1.01.  Ablation builds of THIS
+// kernel say where the rest is: without stores 0.48 / 0.81 ms, without loads 0.39 / 0.67, without split + MFMA 0.60 (stage 3) -- a plain
+// copy of the same slabs in the same 128-byte / 256-byte runs takes 0.41 ms (tools/run_granularity.hip: 5.3 TB/s whatever the run
+// length), so neither the bytes nor the run length is the bound; it is how many loads, stores and dependent waits one wave threads
+// through one in-order vmcnt counter.  Tried and rejected: 32-column units with a ring of four register windows (three chunks ahead:
+// MORE waiting, 0.75 ms), three waves per SIMD (168 VGPRs: 25-38 spilled dwords), non-temporal loads / stores (+14 ... +34 %),
+// 8-byte-aligned pair stores (-4 %, needs a cross-lane exchange) and no second tap load (-5 %).
+// ABL (diagnostic builds only, -DVV_UP2_DIAG + VV_UP2_ABLATE in the environment): 1 = no stores, 2 = no loads, 3 = no split / MFMA,
+// 4 = non-temporal loads, 5 = non-temporal stores, 6 = both, 7 = pair stores moved to an 8-byte boundary (wrong data: timing only),
+// 8 = the tap at q - 1 not loaded (copied from the tap at q: wrong data, timing only), 9 = 7 + 8
+template <int NCH, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up2_stream_x3_kernel(
     const float* __restrict__ in, const u32x4* __restrict__ Wb, const float* __restrict__ bias, float* __restrict__ out, int rows_pad, int T_in,
     int T_out, int Cout, float pre_slope, float out_scale, const int* __restrict__ len_in, int n_qb, int n_rt, int n_units) {
@@ -339,17 +350,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int tap = 0; tap < 2; ++tap) {
+                if ((ABL == 8 || ABL == 9) && tap == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[ti][1][j] = x[ti][0][j];
+                    continue;
+                }
                 const int time = q0 + ti * 32 + r32 - tap;
                 // one vector offset per (time tile, tap); the channel step j * T_in goes into the SCALAR offset, which the range check
                 // ignores: an invalid column keeps its offset past num_records for all 8 loads and reads zero
                 const unsigned off = (time >= 0 && time < lin) ? (unsigned)(c0 * T_in + time) * 4u : 0x80000000u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    x[ti][tap][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, j * T_in * 4, 0));
+                    x[ti][tap][j] = ABL == 2 ? __uint_as_float(off + j)
+                                             : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, j * T_in * 4, (ABL == 4 || ABL == 6) ? 2 : 0));
             }
     };
     f32x16 acc[2][2];
     auto compute = [&](const xbuf_t& x, int ch) {
+        if (ABL == 3) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[kw][ti][j] += x[ti][kw][j];
+            return;
+        }
 #pragma unroll
         for (int kw = 0; kw < 2; ++kw) {
             bf16x8 a[2][3], xf[2][3];
@@ -409,10 +435,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float v0 = acc[ri][ti][r] + bv, v1 = acc[ri][ti][r + 1] + bv;
                     v0 *= out_scale; v1 *= out_scale;
                     const unsigned e = (unsigned)(co * T_out + 2 * q - 1);
-                    if (q >= 1 && q < T_in) {
+                    if (ABL == 1) {
+                        if (v0 == 123.456f && v1 == 654.321f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rs_out, (int)(e * 4u), 0, 0);
+                    } else if (q >= 1 && q < T_in) {
                         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
                         const u32x2 pv = {__float_as_uint(v0), __float_as_uint(v1)};
-                        __builtin_amdgcn_raw_buffer_store_b64(pv, rs_out, (int)(e * 4u), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(pv, rs_out, (int)((e + ((ABL == 7 || ABL == 9) ? 1u : 0u)) * 4u), 0, (ABL == 5 || ABL == 6) ? 2 : 0);
                     } else if (q == 0) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rs_out, (int)((e + 1u) * 4u), 0, 0);
                     } else if (q == T_in) {
@@ -461,10 +489,27 @@ hipError_t launch_x3_t(const vv_conv_args* a, hipStream_t st) {
                                                               n_tt, n_rt, n_tt * a->B);
     return hipGetLastError();
 }
-template <int NCH>
+template <int NCH, int ABL = 0>
 hipError_t launch_up2_stream(const vv_conv_args* a, hipStream_t st) {
+#ifdef VV_UP2_DIAG
+    if (ABL == 0) {
+        const char* e = getenv("VV_UP2_ABLATE");
+        switch (e ? atoi(e) : 0) {
+            case 1: return launch_up2_stream<NCH, 1>(a, st);
+            case 2: return launch_up2_stream<NCH, 2>(a, st);
+            case 3: return launch_up2_stream<NCH, 3>(a, st);
+            case 4: return launch_up2_stream<NCH, 4>(a, st);
+            case 5: return launch_up2_stream<NCH, 5>(a, st);
+            case 6: return launch_up2_stream<NCH, 6>(a, st);
+            case 7: return launch_up2_stream<NCH, 7>(a, st);
+            case 8: return launch_up2_stream<NCH, 8>(a, st);
+            case 9: return launch_up2_stream<NCH, 9>(a, st);
+            default: break;
+        }
+    }
+#endif
     static X3Setup setup;
-    auto kern = up2_stream_x3_kernel<NCH>;
+    auto kern = up2_stream_x3_kernel<NCH, ABL>;
     const int lds = NCH * 768 * 16;
     if (hipError_t he = setup.ensure((const void*)kern, lds); he != hipSuccess) return he;
     const int n_qb = (a->T_in + 1 + 63) / 64, n_rt = a->rows_total / 64;
