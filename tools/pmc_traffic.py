@@ -36,7 +36,8 @@ def load(dirname, counter):
 
 
 def short(name):
-    return name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "").strip()[:120]
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")          # demangled names: strip these BEFORE cutting at the argument list
+    return name.split("(")[0].strip()[:120]
 
 
 def main():
