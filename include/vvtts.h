@@ -165,6 +165,9 @@ VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
  * the other's kernels.  A single item runs its two CFG branches (conditional / unconditional rows) as the lanes, forked and joined once
  * per Euler step.  0 (default) = for the bf16 model from 1,024 packed rows (2 x sum of the lengths) on, 1 = never, 2 = always.
  * Results are bit-identical: every row's arithmetic is independent of what shares its launch.
+ * "ring_tiles": 1 (default) = bf16 GEMMs of the path with N <= 1024 whose 64-token x 128-feature tiles are fewer than the CUs (the
+ * out-projection and FF2 of a single utterance's CFG branch) take 64 x 64 tiles on a three-stage LDS ring (vv_gemm tile 6464); 0 = never;
+ * n > 1 = the same with n as the tile-count bound.  Same bits either way.
  * "pp_min_tiles": -1 (default) = vv_gemm's own choice between its persistent 256 x 256 kernel and the 128 x 128 one; n >= 0 = the
  * persistent kernel for every bf16 GEMM of the path with M >= 4096, N % 256 == 0 and >= n 256-tiles.  Same bits either way. */
 VV_API int vv_set_option(vv_ctx* ctx, const char* name, int value);

@@ -9,8 +9,11 @@ against the digests the generator stored -- a generator that changed silently fa
 
 Tolerances follow tests/test_fullsize_gpu.py: the fixture carries how far the plain-torch fp32 oracle is from the float64 one at
 every kept step (after 31 steps: max |err| 4.7e-4, rmse / rms 2.3e-5 on a state of range 12, PCM +-1 LSB); the HIP fp32 path is
-held to a small multiple of THAT (it cannot be held to SURVEY's 1e-4: no fp32 implementation meets it), the bf16 path to 2 x the
-figures measured when the test was written.  PARITY UNPINNED against the real reference graphs (oracle/vv_oracle.py header).
+held to a small multiple of THAT (it cannot be held to SURVEY's 1e-4: no fp32 implementation meets it).  The bf16 path is held to an
+INDEPENDENT yardstick since round 5 (tests/golden/fullsize_bf16_yardstick.*): the float64 oracle with bf16 roundings at the bf16
+model's storage points (oracle/vv_oracle_bf16.py), all 31 steps of item 0 -- what the bf16 FORMAT costs, measured without any
+kernel of the product (rounds 3-4 used "2 x what the same kernels produced").  PARITY UNPINNED against the real reference graphs
+(oracle/vv_oracle.py header).
 """
 import hashlib
 import json
@@ -51,6 +54,16 @@ def gold():
     for k, h in meta["inputs"]["weights"].items():
         assert _digest(w[k]) == h, k
     return dict(meta=meta, arr=arr, spec=spec, w=w, d=d, N=N)
+
+
+@pytest.fixture(scope="module")
+def yard(gold):
+    with open(os.path.join(GOLD, "fullsize_bf16_yardstick.json")) as fh:
+        ym = json.load(fh)
+    assert ym["inputs"] == gold["meta"]["inputs"] and ym["nfe_step"] == 32 and ym["item"] == 0 and ym["steps"] == 31
+    state = {int(k): v["rmse_over_rms"] for k, v in ym["yardstick_vs_f64"].items()}
+    return dict(meta=ym, arr=np.load(os.path.join(GOLD, "fullsize_bf16_yardstick.npz")), state=state,
+                wave=ym["yardstick_wave_vs_f64"]["rmse_over_rms"], pcm=ym["yardstick_wave_vs_f64"]["pcm_rmse_over_rms"])
 
 
 def _run31(eng, d, N, keep):
@@ -104,53 +117,45 @@ def test_fp32_production_run_matches_the_oracle_fixture(gold):
     assert not bad, bad
 
 
-def test_bf16_production_run_close_to_the_oracle_fixture(gold):
-    """configs[2]'s arithmetic (bf16 acoustic + fp32-fidelity vocoder) at B = 1 with the production step count."""
+def test_bf16_production_run_is_the_price_of_the_format(gold, yard):
+    """configs[2]'s arithmetic (bf16 acoustic + fp32-fidelity vocoder) at B = 1 with the production step count, against the float64
+    fixture -- and the error it may have is the independent yardstick's (the float64 oracle with bf16 storage roundings): within
+    +-10 % of it at every kept step and at the waveform (measured round 5: 1.834e-5 / 9.016e-4 / 2.91e-3 / 4.49e-3 / 5.17e-3 and 5.06e-3
+    against the yardstick's 1.832e-5 / 9.046e-4 / 2.919e-3 / 4.507e-3 / 5.191e-3 and 5.080e-3: the same to three digits).  Two-sided:
+    more than the format's price is a defect, far less means the run is not the bf16 model."""
     from vietvoice_tts_amd.runtime import HipSynth
     g, meta = gold, gold["meta"]
     keep = meta["keep_steps"]
     eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
     _pre, states, pcm, pcm_len, wave = _run31(eng, g["d"], g["N"], keep)
     eng.close()
-    # bounds = 2 x the figures measured when the test was written (round 3; BF16_MEASURED below), so a regression that doubles
-    # the bf16 error fails
-    got = {}
+    bad = []
     for k in keep:
         ref = torch.from_numpy(g["arr"][f"x{k}"]).double()
         err = (states[k] - ref).abs()
-        got[k] = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-        print(f"\n[full bf16, 31 steps] after step {k:2d}: state rmse/rms {got[k]:.3e}, max abs err {float(err.max()):.3e}")
+        got = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        print(f"\n[full bf16, 31 steps] after step {k:2d}: state rmse/rms {got:.3e} (yardstick {yard['state'][k]:.3e}), max abs err {float(err.max()):.3e}")
+        if not 0.9 * yard["state"][k] - 2e-7 <= got <= 1.1 * yard["state"][k] + 2e-7:
+            bad.append((k, got, yard["state"][k]))
     n = g["arr"]["pcm"].size
     ref_w = torch.from_numpy(g["arr"]["wave"]).double()
     wr = float((wave[:n] - ref_w).pow(2).mean().sqrt() / ref_w.pow(2).mean().sqrt())
-    print(f"[full bf16, 31 steps] waveform rmse/rms {wr:.3e}")
+    print(f"[full bf16, 31 steps] waveform rmse/rms {wr:.3e} (yardstick {yard['wave']:.3e})")
     assert pcm_len == n and bool(torch.isfinite(wave).all()) and int(pcm[:n].abs().max()) > 0
-    for k in keep:
-        assert got[k] <= 2.0 * BF16_MEASURED[k], (k, got[k])
-    assert wr <= 2.0 * BF16_MEASURED["wave"], wr
+    if not 0.9 * yard["wave"] <= wr <= 1.1 * yard["wave"]:
+        bad.append(("wave", wr, yard["wave"]))
+    assert not bad, bad
 
 
-def test_bf16_run_against_the_independent_bf16_yardstick(gold):
-    """what the bf16 path may cost is taken from an INDEPENDENT source, not from what the same kernels produced earlier:
-    tests/golden/fullsize_bf16_yardstick.* holds bench item 0 through the float64 oracle that rounds to bf16 exactly where the bf16
-    model stores bf16 (oracle/vv_oracle_bf16.py: GEMM / attention operands, activations between kernels; sums, norms, transcendentals and
-    the residual stream stay float64), for the first Euler steps of the production grid, next to the plain float64 run of the same
-    steps.  yardstick - float64 = the price of the FORMAT.  The HIP bf16 path is held to it at every kept step:
-      (a) its error against float64 is the yardstick's within +-10 % (measured round 5: 1.834e-5 / 2.479e-4 / 9.016e-4 / 1.864e-3
-          against 1.832e-5 / 2.485e-4 / 9.046e-4 / 1.871e-3 after steps 1 / 4 / 8 / 12: the same to three digits -- it loses what the
-          format costs and nothing else: fp32 accumulation, approximate exp2 / rope angles and double roundings are inside the margin;
-          a truncating conversion, a bf16 accumulator or a missing fp32 residual would not be; and an error far BELOW the format's
-          price would mean the run is not the bf16 model at all), and
-      (b) it is no further from the yardstick than 1.2 x the format's price (measured 0.69-0.94 x: two realisations of the same
-          rounding noise decorrelate as the perturbation flips roundings downstream, so their distance approaches sqrt(2) x only for
-          a path with a DIFFERENT error mechanism; a systematic deviation shows here first)."""
+def test_bf16_run_stays_near_the_yardstick_trajectory(gold, yard):
+    """VERDICT r4 #8, the second half: besides costing what the format costs (the test above), the HIP bf16 run must stay NEAR the
+    yardstick's own trajectory: after steps 1 / 4 / 8 / 12 its distance to the yardstick state is at most 1.2 x the format's price
+    (measured 0.69 - 0.94 x: two realisations of one rounding noise decorrelate as a perturbation flips roundings downstream and
+    approach sqrt(2) x only for a path with a DIFFERENT error mechanism; a systematic deviation shows here first), and its error
+    against float64 is the yardstick's within +-10 % at the intermediate steps the 31-step test does not keep."""
     from vietvoice_tts_amd.runtime import HipSynth
-    g = gold
-    with open(os.path.join(GOLD, "fullsize_bf16_yardstick.json")) as fh:
-        ym = json.load(fh)
-    ya = np.load(os.path.join(GOLD, "fullsize_bf16_yardstick.npz"))
-    assert ym["inputs"] == g["meta"]["inputs"] and ym["nfe_step"] == 32 and ym["item"] == 0
-    keep = ym["keep_steps"]
+    g, ym, ya = gold, yard["meta"], yard["arr"]
+    keep = [k for k in ym["array_steps"] if k <= 12]
     one = {k: v[0:1].contiguous().to(DEV) for k, v in g["d"].items() if torch.is_tensor(v)}
     eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
     pre = eng.preprocess(one["audio"], one["audio_len"], one["ids"], one["text_len"], one["seq_len"], g["N"], seq_len_host=[g["N"]])
@@ -162,8 +167,8 @@ def test_bf16_run_against_the_independent_bf16_yardstick(gold):
         got = x[0].cpu().double()
         src = ym["f64_states"][str(k)]                       # the float64 state: in this fixture, or the one fullsize_golden.npz already holds
         f64 = torch.from_numpy(g["arr"][src.split(":")[1]] if ":" in src else ya[src]).double()
-        yard = torch.from_numpy(ya[f"yard_x{k}"]).double()
-        e_hip, e_yard, d_hy = rel(got, f64), ym["yardstick_vs_f64"][str(k)]["rmse_over_rms"], rel(got, yard)
+        yd = torch.from_numpy(ya[f"yard_x{k}"]).double()
+        e_hip, e_yard, d_hy = rel(got, f64), yard["state"][k], rel(got, yd)
         print(f"\n[full bf16 vs yardstick] after step {k:2d}: HIP - f64 {e_hip:.3e} | yardstick - f64 {e_yard:.3e} | HIP - yardstick {d_hy:.3e}")
         if not 0.9 * e_yard - 2e-7 <= e_hip <= 1.1 * e_yard + 2e-7:
             bad.append(("error vs float64 is not the format's price", k, e_hip, e_yard))
@@ -173,12 +178,14 @@ def test_bf16_run_against_the_independent_bf16_yardstick(gold):
     assert not bad, bad
 
 
-def test_bf16_headline_batch_item0_production_run(gold):
+def test_bf16_headline_batch_item0_production_run(gold, yard):
     """configs[2] itself: the headline batch (B = 32, bench inputs, bf16 acoustic + fp32-fidelity vocoder) through
     `synthesize_batch` -- the call bench.py times -- with the production step count; item 0 of the batch against the oracle fixture
     (same bounds as the single-utterance run: rows are packed and every kernel is row- or sequence-local), the whole batch finite,
     full length and not one utterance repeated; then item 31 -- the last rows of every launch -- against its own fixture, with and
-    without the split-K tail option."""
+    without the split-K tail option.  Bounds: the independent bf16 yardstick's figures for item 0 (tests/golden/
+    fullsize_bf16_yardstick.*): item 0 within +-10 %; another item (31: other text, other clip, other noise) at most 1.15 x (its own
+    error measured 3 % above item 0's)."""
     import bench
     from vietvoice_tts_amd.runtime import HipSynth
     g = gold
@@ -196,7 +203,7 @@ def test_bf16_headline_batch_item0_production_run(gold):
     ref_pcm = torch.from_numpy(g["arr"]["pcm"]).double()
     pr = float((pcm[0, :n].cpu().double() - ref_pcm).pow(2).mean().sqrt() / ref_pcm.pow(2).mean().sqrt())
     print(f"\n[full bf16 B=32, 31 steps] item 0 vs the float64 fixture: state rmse/rms {rm:.3e}, PCM rmse/rms {pr:.3e}")
-    assert rm <= 2.0 * BF16_MEASURED[31] and pr <= 2.0 * BF16_MEASURED["pcm"]
+    assert 0.9 * yard["state"][31] <= rm <= 1.1 * yard["state"][31] and 0.9 * yard["pcm"] <= pr <= 1.1 * yard["pcm"], (rm, pr)
     assert float((x[1] - x[0]).abs().max()) > 1e-2 and float(pcm.float().abs().amax(dim=1).min()) > 0
     # ---- item 31, the LAST item of the batch: its unconditional rows are the last rows of every launch (rows 100,800 .. 102,399 of
     # 102,400: the last row panels of the persistent GEMM, the panels a split-K tail would take), against ITS OWN float64 fixture
@@ -213,7 +220,7 @@ def test_bf16_headline_batch_item0_production_run(gold):
     rp31 = torch.from_numpy(a31["pcm"]).double()
     pr31 = float((pcm[31, :n].cpu().double() - rp31).pow(2).mean().sqrt() / rp31.pow(2).mean().sqrt())
     print(f"[full bf16 B=32, 31 steps] item 31 (last rows of every launch) vs its float64 fixture: state rmse/rms {rm31:.3e}, PCM rmse/rms {pr31:.3e}")
-    assert rm31 <= 2.0 * BF16_MEASURED[31] and pr31 <= 2.0 * BF16_MEASURED["pcm"]
+    assert rm31 <= 1.15 * yard["state"][31] and pr31 <= 1.15 * yard["pcm"], (rm31, pr31)
     # ---- the same item with the split-K tail OPTION on (FF2): its unconditional rows then really are tail rows (K parts summed by the
     # LayerNorm) -- the tail's arithmetic against the oracle, not only against the plain launch
     eng = HipSynth(g["spec"], g["w"], acoustic_dtype="bf16", nfe_step=32)
@@ -225,17 +232,19 @@ def test_bf16_headline_batch_item0_production_run(gold):
     rmt = float((xt[31].cpu().double() - ref31).pow(2).mean().sqrt() / ref31.pow(2).mean().sqrt())
     prt = float((pcmt[31, :n].cpu().double() - rp31).pow(2).mean().sqrt() / rp31.pow(2).mean().sqrt())
     print(f"[full bf16 B=32, 31 steps] item 31 with split_k_tail = 2: state rmse/rms {rmt:.3e}, PCM rmse/rms {prt:.3e}; item 0 unchanged: {bool(torch.equal(xt[0], x[0]))}")
-    assert rmt <= 2.0 * BF16_MEASURED[31] and prt <= 2.0 * BF16_MEASURED["pcm"]
+    assert rmt <= 1.15 * yard["state"][31] and prt <= 1.15 * yard["pcm"], (rmt, prt)
     assert torch.equal(xt[0], x[0]) and not torch.equal(xt[31], x[31])       # item 0 never enters a tail; item 31 does
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_ragged_batch_production_run(dtype):
+def test_ragged_batch_production_run(dtype, yard):
     """BASELINE configs[3] semantics with the production step count at FULL size: three utterances of different reference-clip, text
     and frame lengths as ONE packed ragged batch (per-item masks in attention / pos-conv / text conv, packed GEMM rows, bucketed
     vocoder), all 31 steps; EVERY item (0: 1600 frames at row_start 0, 1: 851, 2: 411) against the float64 oracle run on that item
     ALONE (tests/golden/fullsize_ragged_golden.*, generator `make_fullsize_golden.py --ragged [--items 0]`).  fp32: bounds from the
-    torch-fp32 yardstick in the fixture; bf16 (configs[3]'s arithmetic): 2 x the figures measured when the case was added (round 4)."""
+    torch-fp32 yardstick in the fixture; bf16 (configs[3]'s arithmetic): at most 1.15 x what the bf16 FORMAT costs on the headline item
+    (the independent yardstick of tests/golden/fullsize_bf16_yardstick.*: 5.19e-3 state / 5.08e-3 PCM; these items measured
+    4.93 - 5.09e-3 / 5.08 - 5.10e-3: a packed ragged batch costs no accuracy)."""
     import importlib.util
     import bench  # noqa: F401  (the generator module imports it)
     from vietvoice_tts_amd.model_spec import ModelSpec, make_synthetic_weights
@@ -277,18 +286,10 @@ def test_ragged_batch_production_run(dtype):
               f"{y['max_err']:.2e} / {y['rmse_over_rms']:.2e}; PCM max diff {int(dp.max())} LSB ({int((dp > 0).sum())} of {n} differ; torch-fp32 {y['pcm_max_lsb']} LSB)")
         assert int(pre["ref_signal_len"][b]) == it["ref_signal_len"] and int(pcm_len[b]) == n == gf[b] * spec.hop_length
         if dtype == "bf16":
-            checks += [(f"bf16 state rmse/rms item {b}", rm, 2.0 * BF16_RAGGED_MEASURED[b][0]), (f"bf16 pcm rmse/rms item {b}", pr, 2.0 * BF16_RAGGED_MEASURED[b][1])]
+            checks += [(f"bf16 state rmse/rms item {b}", rm, 1.15 * yard["state"][31]), (f"bf16 pcm rmse/rms item {b}", pr, 1.15 * yard["pcm"])]
             continue
         # measured: item 1 max err 2.9e-3 (2.8 x the torch-fp32 figure, one element of a state of range 12.8) / rmse 1.25 x; item 2 1.07 x / 0.81 x
         checks += [(f"state max err item {b}", mx, 4.0 * y["max_err"] + 2e-6), (f"state rmse item {b}", rm, 2.0 * y["rmse_over_rms"] + 2e-7),
                    (f"pcm lsb item {b}", int(dp.max()), y["pcm_max_lsb"] + 1), (f"pcm share beyond 1 LSB item {b}", float((dp > 1).float().mean()), 1e-4)]
     bad = [c for c in checks if not c[1] <= c[2]]
     assert not bad, bad
-
-
-# state rmse/rms after steps 1, 8, 16, 24, 31 and waveform rmse/rms of the bf16 run above, as first measured (round 3); "pcm" = the
-# int16 PCM's rmse/rms against the fixture's PCM (its own measured figure since round 4: the waveform's plus the quantisation)
-BF16_MEASURED = {1: 1.83e-5, 8: 9.02e-4, 16: 2.91e-3, 24: 4.49e-3, 31: 5.17e-3, "wave": 5.06e-3, "pcm": 5.06e-3}      # items 0 / 31: 5.36e-3 state, 5.09e-3 PCM
-# bf16 ragged batch, per item: (state rmse/rms after 31 steps, PCM rmse/rms) as first measured (round 4: 4.95e-3 / 5.10e-3, 4.93e-3 /
-# 5.09e-3, 5.09e-3 / 5.08e-3 -- the single-utterance class: a packed ragged batch costs no accuracy)
-BF16_RAGGED_MEASURED = {0: (4.95e-3, 5.10e-3), 1: (4.93e-3, 5.09e-3), 2: (5.09e-3, 5.08e-3)}

@@ -562,7 +562,8 @@ def test_computed_rope_matches_the_tables(hip_tiny):
 def test_gemm_three_tilings_give_the_same_bits(hip_tiny, M):
     """Round 4: vv_gemm picks among three bf16 tilings by launch size -- 64-token x 128-feature tiles (launches that do not fill the chip),
     128 x 128, and the persistent 256 x 256 kernel -- and a row's result must not depend on the choice (an item alone and the same item
-    in a batch take different ones).  All three contract K in the same order with the same MFMA from bias-started accumulators and share
+    in a batch take different ones).  Round 5: a fourth, 64 x 64 tiles on a three-stage LDS ring with a counted wait (tile code 6464;
+    K = 512 here is 8 K-tiles: ring start, steady state and drain; K = 64 and 128 -- one and two K-tiles -- in the case below).  All three contract K in the same order with the same MFMA from bias-started accumulators and share
     the epilogue arithmetic: plain store, tanh-GELU store, gate store and the computed-rope QKV epilogue are EQUAL arrays, ragged M
     included (the last tile of each tiling is partial in a different place); and equal to what the automatic choice produces."""
     rt, gu = _imports()
@@ -580,14 +581,34 @@ def test_gemm_three_tilings_give_the_same_bits(hip_tiny, M):
              "rope": dict(mode=1, ropes=ropes, seq_n=800, rope_dim=512, rope_theta=10000.0)}
     y = A.float() @ W.float().t() + b
     for name, kw in forms.items():
-        outs = {t: gu.gemm(eng, A, W, bias=b, tile=t, **kw) for t in (64, 128, 256, 0)}
+        outs = {t: gu.gemm(eng, A, W, bias=b, tile=t, **kw) for t in (64, 128, 256, 0, 6464)}
         outs["shared"] = gu.gemm(eng, A, W, bias=b, tile=0, chip_share=2, **kw)      # the automatic choice priced for half of the chip
-        for t in (128, 256, 0, "shared"):
+        for t in (128, 256, 0, "shared", 6464):
             assert torch.equal(outs[t], outs[64]), (name, t, float((outs[t].float() - outs[64].float()).abs().max()))
         if name == "store":
             assert gu.rel_err(outs[64], y) < TOL_BF16
         if name == "gate":
             assert gu.rel_err(outs[64], gate * y) < TOL_BF16
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 2048])
+def test_gemm_ring_tiling_short_and_long_k(hip_tiny, K):
+    """The three-stage ring of the 64 x 64 tiling at the ends of its range: one K-tile (nothing to prefetch), two (no steady state), three,
+    and the FF2 depth (32 K-tiles), ragged M, gate store: equal to the 128 x 128 kernel bit for bit, fresh rows past M untouched."""
+    rt, gu = _imports()
+    eng = hip_tiny["f32"]
+    g = torch.Generator().manual_seed(K)
+    M, N = 1600 + 37, 1024
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gu.DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(gu.DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(gu.DEV)
+    gate = torch.randn(N, generator=g).to(gu.DEV)
+    for kw in (dict(), dict(mode=3, gate=gate)):
+        ref = gu.gemm(eng, A, W, bias=b, tile=128, **kw)
+        for rep in range(3):                                   # the ring is a race if its counts are wrong: more than one launch
+            for t in (6464,):
+                got = gu.gemm(eng, A, W, bias=b, tile=t, **kw)
+                assert torch.equal(got, ref), (K, t, kw.keys(), rep, float((got.float() - ref.float()).abs().max()))
 
 
 def test_attention_spiked_max(hip_tiny):

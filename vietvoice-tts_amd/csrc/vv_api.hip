@@ -54,6 +54,8 @@ struct vv_ctx {
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
     int chip_share = 1;                 // 2 while a call runs two lanes (vv_gemm_args.chip_share of its GEMM launches)
+    int ring_tiles_max = 256;           // the tile-count bound of that rule (the CU count)
+    int ring_tiles = 1;                 // 1 (default since round 5; same bits): N <= 1024 bf16 GEMMs whose 64 x 128 tiles are fewer than the CUs take the 64 x 64 three-stage-ring tiling (vv_gemm tile 6464)
     int pp_min_tiles = -1;              // bf16 GEMMs of the path: -1 = the launcher's own choice between the persistent 256 x 256 kernel and the 128 x 128 one
                                         // (vv_gemm.hip launch(): about one full round of 256-tiles, or the wide QKV shape); n >= 0 = the persistent
                                         // kernel whenever M >= 4096, N % 256 == 0 and the shape has >= n 256-tiles (0 = the rule of rounds 1-3; lets a
@@ -174,6 +176,8 @@ int gemm(vv_ctx* c, int dtype, int out_dtype, int mode, int act, const void* A, 
     if (!g.W) return c->fail(-2, "weight '%s' is not bound", wname);
     if (c->pp_min_tiles >= 0 && dtype == VV_DTYPE_BF16 && N % 256 == 0)
         g.tile = (M >= 4096 && (long long)((M + 255) / 256) * (N / 256) >= c->pp_min_tiles) ? 256 : 128;
+    if (c->ring_tiles && g.tile == 0 && dtype == VV_DTYPE_BF16 && N <= 1024 && N % 64 == 0 && (long long)((M + 63) / 64) * (N / 128) <= c->ring_tiles_max)
+        g.tile = 6464;
     const int esz = dtype == VV_DTYPE_BF16 ? 2 : 4, osz = out_dtype == VV_DTYPE_BF16 ? 2 : 4;
     const double fl = alg_flops >= 0 ? alg_flops : 2.0 * M * (double)N * K;
     Prof p(c, VV_PROF_GEMM, fl, (double)M * K * esz + (double)N * K * esz + (double)M * N * osz * (mode == VV_EPI_GATE_RES ? 2 : 1), st);
@@ -943,6 +947,7 @@ int vv_set_option(vv_ctx* c, const char* name, int value) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: split_k_tail takes 0 (off), 1 (out-projection and FF2) or 2 (FF2 only)");
         c->split_k_tail = value; return 0;
     }
+    if (!strcmp(name, "ring_tiles")) { c->ring_tiles = value != 0; if (value > 1) c->ring_tiles_max = value; return 0; }
     if (!strcmp(name, "pp_min_tiles")) {
         if (value < -1) return c->fail(-22, "vv_set_option: pp_min_tiles takes -1 (the launcher's rule) or a 256-tile count >= 0");
         c->pp_min_tiles = value; return 0;

@@ -146,22 +146,45 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, To* C, int ldc, int 
     }
 }
 
+// LDS-DMA as an asm statement (as in vv_attention.hip): outside hipcc's waitcnt bookkeeping, so a COUNTED s_waitcnt vmcnt(N) can leave a
+// younger stage in flight (the builtin form makes hipcc put vmcnt(0) in front of the next LDS read).  Used by the three-stage ring of CFG 4.
+typedef __attribute__((ext_vector_type(4))) int gemm_i32x4_t;
+__device__ __forceinline__ gemm_i32x4_t gemm_rsrc4(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    gemm_i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void gemm_glds16_asm(gemm_i32x4_t rs, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
 template <typename T, int MODE, typename To, int CFG>
-__global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 ? 4 : (CFG == 3 ? 3 : 2)) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
+__global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 ? 4 : ((CFG == 3 || CFG == 4) ? 3 : 2)) void gemm_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
                                                                   int ldw, To* __restrict__ C, int ldc, int M, int N, int K,
                                                                   EpiArgs e, int m_tiles, int n_tiles) {
     constexpr int BK = GemmTraits<T>::BK;
     // CFG 0: 128 x 128 tile, 4 waves (64 tokens x 64 features each); 1 / 2: 256 x 256 with 8 / 16 waves; 3 (bf16 only): 64 tokens x 128
-    // features, 4 waves of 32 x 64 -- twice the workgroups for launches whose 128-tiles do not fill the chip (single utterances)
+    // features, 4 waves of 32 x 64 -- twice the workgroups for launches whose 128-tiles do not fill the chip (single utterances);
+    // 4 (bf16 only, round 5): 64 tokens x 64 features, 4 waves of 32 x 32, THREE-stage LDS ring with a counted wait -- for the N = 1024
+    // GEMMs of a single utterance's CFG branch, whose 64 x 128 tiles are fewer than the CUs: a workgroup alone on its CU pays the full
+    // L2 latency per K-tile in the two-stage loop (0.9 - 1.1 us per K-tile measured), the ring keeps two K-tiles in flight
     constexpr bool BIG = CFG == 1 || CFG == 2;
-    constexpr int BT = BIG ? 256 : 128;            // rows of W (features) per tile
-    constexpr int BTM = CFG == 3 ? 64 : BT;        // rows of A (tokens) per tile
+    constexpr bool RING3 = CFG == 4;                              // (the 64 x 128 tile on the same ring was measured too: FF2 alike, QKV / FF1 10 - 30 % slower)
+    constexpr int BT = BIG ? 256 : (RING3 ? 64 : 128);            // rows of W (features) per tile
+    constexpr int BTM = (CFG == 3 || RING3) ? 64 : BT;            // rows of A (tokens) per tile
     constexpr int A_BYTES = BTM * 128, W_BYTES = BT * 128;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int MW = CFG == 1 ? 128 : (CFG == 3 ? 32 : 64);        // tokens per wave
+    constexpr int MW = CFG == 1 ? 128 : ((CFG == 3 || RING3) ? 32 : 64);        // tokens per wave
+    constexpr int NW16 = RING3 ? 2 : 4;                           // 16-feature blocks per wave (features per wave = 32 or 64)
     constexpr int NWAVE = CFG == 2 ? 16 : (CFG == 1 ? 8 : 4);
     constexpr int PPA = BTM / 8 / NWAVE, PPW = BT / 8 / NWAVE;       // LDS-DMA pieces per wave per tile (A, W)
-    static_assert(CFG != 3 || sizeof(T) == 2, "the 64-token tile exists for bf16 only");
+    static_assert((CFG != 3 && CFG != 4) || sizeof(T) == 2, "the 64-token tiles exist for bf16 only");
     // (a four-stage ring with counted waits, one workgroup per CU, was measured SLOWER for the single-utterance shapes than this
     // two-stage loop at two workgroups per CU: 97.9 against 94.1 ms of GEMM per utterance, profiles/r03/gemm_notes.md)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile | W tile)
@@ -204,24 +227,61 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
     };
 
     const int nk = K / BK;
-    stage(0, 0);
-    auto ring_step = [&](int kt) __attribute__((always_inline)) {       // top of K-tile kt: its pieces have landed, the other stage is free
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    constexpr int NST = RING3 ? 3 : 2;
+    // ---- CFG 4: the same pieces through buffer_load ... lds as asm statements (rows past M read zeros: their offset is past num_records)
+    const gemm_i32x4_t rs_a = gemm_rsrc4(A, (unsigned)min((size_t)M * lda * sizeof(T), (size_t)0x7fffffff));
+    const gemm_i32x4_t rs_w = gemm_rsrc4(W, (unsigned)min((size_t)N * ldw * sizeof(T), (size_t)0x7fffffff));
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned voff_a[PPA], voff_w[PPW];
+    if constexpr (RING3) {
+#pragma unroll
+        for (int u = 0; u < PPA; ++u) {
+            const int row = (wave * PPA + u) * 8 + (lane >> 3);
+            voff_a[u] = (unsigned)(bm + row) * (unsigned)lda * 2u + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+            const int row = (wave * PPW + u) * 8 + (lane >> 3);
+            voff_w[u] = (unsigned)(bn + row) * (unsigned)ldw * 2u + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+        }
+    }
+    auto stage3 = [&](int kt, int buf) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + (unsigned)(buf * STAGE_BYTES), koff = (unsigned)kt * 128u;
+#pragma unroll
+        for (int u = 0; u < PPA; ++u) gemm_glds16_asm(rs_a, voff_a[u] + koff, dst + (unsigned)((wave * PPA + u) * 1024));
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) gemm_glds16_asm(rs_w, voff_w[u] + koff, dst + (unsigned)(A_BYTES + (wave * PPW + u) * 1024));
     };
-    constexpr int NST = 2;
+    if constexpr (RING3) { stage3(0, 0); if (nk > 1) stage3(1, 1); }
+    else stage(0, 0);
+    auto ring_step = [&](int kt) __attribute__((always_inline)) {       // top of K-tile kt: its pieces have landed, the other stage is free
+        if constexpr (RING3) {
+            // INVARIANT (asm LDS-DMA is outside hipcc's bookkeeping): a wave has issued stages <= kt + 1 here, PPA + PPW pieces each, and
+            // nothing else counts in vmcnt inside the loop -- so "all but the youngest PPA + PPW" = stage kt has landed for this wave, and
+            // behind the barrier for every wave.  Stage kt + 2 goes into the buffer tile kt - 1 was read from: every wave has passed this
+            // barrier only after its last LDS read of tile kt - 1 was consumed by an MFMA.
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPA + PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage3(kt + 2, (kt + 2) % 3);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        }
+    };
 
     if constexpr (sizeof(T) == 2) {
         // ------------------------------------------------ bf16: 4 x (MW/16) tiles of 16x16x32
         constexpr int MI = MW / 16;
-        f32x4 acc[4][MI];
+        f32x4 acc[NW16][MI];
+        constexpr int WF = NW16 * 16;      // features per wave
         const int r16 = lane & 15, cq = lane >> 4;
         // accumulators start at the bias (feature-only), as in the persistent kernel: the same fp32 sum, bit for bit
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NW16; ++i) {
             f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * 64 + i * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+            if (e.bias) { const float4 t = *(const float4*)(e.bias + bn + wc * WF + i * 16 + cq * 4); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = b4;
         }
@@ -231,15 +291,15 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             const char* sw = sa + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 wf[4], af[MI];
+                bf16x8 wf[NW16], af[MI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(sw + swz128(wc * 64 + i * 16 + r16, ks * 4 + cq));
+                for (int i = 0; i < NW16; ++i) wf[i] = *(const bf16x8*)(sw + swz128(wc * WF + i * 16 + r16, ks * 4 + cq));
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + swz128(wr * MW + i * 16 + r16, ks * 4 + cq));
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NW16; ++ni)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
         }
@@ -247,7 +307,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
         if (MODE == MODE_STORE && e.act != VV_ACT_NONE) {
             if (e.act == VV_ACT_GELU_ERF) {              // the persistent kernel never takes erf-GELU: no second formula to agree with
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NW16; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -256,7 +316,7 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
                 float k1, k3;
                 act_consts(e.act, k1, k3);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NW16; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -272,8 +332,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             if (m >= M) continue;
             const int pos = (MODE == MODE_QKV_ROPE) ? (e.pos_tab ? e.pos_tab[m] : m % e.seq_n) : 0;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                epi_store<MODE, To>(e, C, ldc, m, pos, bn + wc * 64 + ni * 16 + cq * 4, acc[ni][mi][0], acc[ni][mi][1],
+            for (int ni = 0; ni < NW16; ++ni)
+                epi_store<MODE, To>(e, C, ldc, m, pos, bn + wc * WF + ni * 16 + cq * 4, acc[ni][mi][0], acc[ni][mi][1],
                                     acc[ni][mi][2], acc[ni][mi][3]);
         }
     } else {
@@ -977,9 +1037,9 @@ hipError_t launch_pp(const void* A, int lda, const void* W, int ldw, void* C, in
 template <typename T, int MODE, typename To, int CFG>
 hipError_t launch_t(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K, const EpiArgs& e,
                     hipStream_t st) {
-    constexpr int BT = (CFG == 1 || CFG == 2) ? 256 : 128;
-    constexpr int BTM = CFG == 3 ? 64 : BT;
-    constexpr int LDS = 2 * (BT + BTM) * 128;
+    constexpr int BT = (CFG == 1 || CFG == 2) ? 256 : (CFG == 4 ? 64 : 128);
+    constexpr int BTM = (CFG == 3 || CFG == 4) ? 64 : BT;
+    constexpr int LDS = (CFG == 4 ? 3 : 2) * (BT + BTM) * 128;
     static KernelSetup setup;
     auto kern = gemm_kernel<T, MODE, To, CFG>;
     if (hipError_t he = setup.ensure((const void*)kern, LDS, nullptr); he != hipSuccess) return he;
@@ -1014,6 +1074,11 @@ hipError_t launch(const void* A, int lda, const void* W, int ldw, void* C, int l
         // launches that do not fill the chip -- every GEMM of a single utterance's CFG branch (M = 1,600: block sum 88 -> 73 us), the
         // N = 1024 shapes up to M = 4,800 -- run 8 - 29 % shorter; all 24 measured (shape, M) pairs agree with the rule
         // (profiles/r04/gemm_tile64_by_m.txt).  Same bits: only the token rows of a tile change.
+        // 64 x 64 tiles on the three-stage ring (CFG 4), tile code 6464: explicit here; the path's rule is vv_api.hip's (option "ring_tiles":
+        // bf16 GEMMs with N <= 1024 whose 64 x 128 tiles are fewer than the CUs -- the out-projection and FF2 of a single utterance's
+        // CFG branch: 10.5 -> 9.7 us and 21.6 -> 17.5 us at M = 1,600, B = 1 113.1 -> 109.1 ms; profiles/r05/gemm_notes.md)
+        if (force_tile == 6464 && (size_t)M * lda * sizeof(T) < ((size_t)1 << 31) && (size_t)N * ldw * sizeof(T) < ((size_t)1 << 31))
+            return launch_t<T, MODE, To, 4>(A, lda, W, ldw, C, ldc, M, N, K, e, st);
         bool t64 = force_tile == 64;
         if (force_tile == 0) {
             // (a launch that shares the chip with another lane's launches is priced for its share: what 64-token tiles gain by reaching
@@ -1044,7 +1109,7 @@ int vvk_gemm(const vvk_gemm_args* g, hipStream_t st, const char** err) {
     if (((size_t)g->lda * esz) % 16 || ((size_t)g->ldw * esz) % 16 || ((uintptr_t)g->A % 16) || ((uintptr_t)g->W % 16) ||
         ((uintptr_t)g->C % 16) || (g->ldc % 4)) { *err = "gemm: operands must be 16-byte aligned"; return -22; }
     if (g->lda < g->K || g->ldw < g->K) { *err = "gemm: leading dimension smaller than K"; return -22; }
-    if (g->tile != 0 && g->tile != 128 && g->tile != 256 && !(g->tile == 64 && g->dtype == VV_BF16)) { *err = "gemm: tile must be 0 (auto), 128, 256, or 64 (bf16)"; return -22; }
+    if (g->tile != 0 && g->tile != 128 && g->tile != 256 && !((g->tile == 64 || g->tile == 6464) && g->dtype == VV_BF16)) { *err = "gemm: tile must be 0 (auto), 128, 256, or 64 / 6464 (bf16)"; return -22; }
     if (g->tile == 256 && g->N % 256) { *err = "gemm: the 256 tile needs N % 256 == 0"; return -22; }
     EpiArgs e{};                 // value-initialised: a field this function forgets is zero, never stack garbage
     e.cs_q = g->rope_cs_q; e.cs_k = g->rope_cs_k;
