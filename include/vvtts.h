@@ -204,7 +204,8 @@ typedef struct vv_gemm_args {
     const float *rope_cs_q, *rope_cs_k;   /* optional compact [pos][64] (cos,sin) pair tables, see vv_rope_compact */
     int32_t tile;   /* 0 = auto (bf16: the persistent 256x256 kernel when M >= 4096, N % 256 == 0 and the shape has at least one round of
                        256-tiles for the chip's CUs or N >= 3072, below that 128x128 tiles or, for launches that do not fill the chip, 64-token x 128-feature
-                       tiles; fp32: 256x256 when M >= 4096 and N % 256 == 0), 128 or 256 to force (bf16: also 64).  Every bf16 choice gives the same bits */
+                       tiles; fp32: 256x256 when M >= 4096 and N % 256 == 0), 128 or 256 to force (bf16: also 64, and 6464 = 64 x 64 tiles on a three-stage
+                       LDS ring).  Every bf16 choice gives the same bits */
     const int32_t* rope_pos;   /* optional [M]: rope position of each row (packed ragged rows); default row % seq_n */
     int32_t rope_by_row;       /* 1: rope_cs_q / rope_cs_k are [M][64] tables gathered per row by vv_rope_rows (the persistent kernel then
                                   needs no position lookup); the cos/sin tables + rope_pos still serve the other kernels */
