@@ -2,7 +2,7 @@
 # Round-end evidence on the GPU box (through gpurun from the repo root):  bash tools/round_end.sh r03
 # the whole -m gpu suite, the headline bench, the rocprofv3 kernel-trace summary of the same command, the other BASELINE configurations.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
