@@ -165,7 +165,6 @@ VV_API int vv_set_rope_theta(vv_ctx* ctx, float theta);
  * the other's kernels.  A single item runs its two CFG branches (conditional / unconditional rows) as the lanes, forked and joined once
  * per Euler step.  0 (default) = for the bf16 model from 1,024 packed rows (2 x sum of the lengths) on, 1 = never, 2 = always.
  * Results are bit-identical: every row's arithmetic is independent of what shares its launch.
- * "attn_ring": vv_attn_args.ring of the path's attention launches (0 = auto, the default; 2; 3).  Same bits.
  * "ring_tiles": 1 (default) = bf16 GEMMs of the path with N <= 1024 whose 64-token x 128-feature tiles are fewer than the CUs (the
  * out-projection and FF2 of a single utterance's CFG branch) take 64 x 64 tiles on a three-stage LDS ring (vv_gemm tile 6464); 0 = never;
  * n > 1 = the same with n as the tile-count bound.  Same bits either way.
@@ -248,8 +247,6 @@ typedef struct vv_attn_args {
                                   the q tables, which carry the softmax scale): the q columns arrive un-roped (vv_gemm_args.rope_skip_q)
                                   and are roped here, position = row inside the sequence, in fp32 before the one rounding to bf16 the
                                   kernel applies to Q anyway.  NULL = q is already roped */
-    int32_t ring;              /* bf16 kernel: K/V stages in LDS.  0 = auto (3 when the launch has at most two workgroups per CU: single
-                                  utterances; else 2), 2 or 3 to force.  Same bits either way */
 } vv_attn_args;
 VV_API int vv_attention(vv_ctx* ctx, const vv_attn_args* args, void* stream);
 

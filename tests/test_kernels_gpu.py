@@ -611,56 +611,6 @@ def test_gemm_ring_tiling_short_and_long_k(hip_tiny, K):
                 assert torch.equal(got, ref), (K, t, kw.keys(), rep, float((got.float() - ref.float()).abs().max()))
 
 
-@pytest.mark.parametrize("seq_n,lens,packed", [(64, None, False), (128, None, False), (200, None, False), (1600, None, False), (700, [700, 1, 333], False),
-                                               (640, [640, 65, 129], True)])
-def test_attention_three_stage_ring_equals_two_stage(hip_tiny, seq_n, lens, packed):
-    """Round 5: launches of at most two workgroups per CU (single utterances) stage K/V through THREE LDS buffers with a counted wait
-    (vv_attn_args.ring = 3; auto picks it by launch size).  Same instructions on the same values: the output must equal the two-stage
-    kernel's bit for bit -- one tile (nothing to prefetch), two, three, 25 tiles, ragged key lengths, packed rows, the spiked-max redo
-    path, repeated launches (a wrong count is a race, not a constant error)."""
-    rt, gu = _imports()
-    eng = hip_tiny["f32"]
-    D, heads = 128, 2
-    g = torch.Generator().manual_seed(seq_n)
-    n_seq = len(lens) if lens else 2
-    kv = lens if lens else [seq_n] * n_seq
-    if packed:
-        starts = [0]
-        for L in kv[:-1]:
-            starts.append(starts[-1] + L)
-        rows = sum(kv)
-    else:
-        starts, rows = None, n_seq * seq_n
-    qkv = (torch.randn(rows, 3 * D, generator=g) * 0.5)
-    qkv[min(5, rows - 1), :64] = 3.0
-    qkv[min(40, rows - 1), D:D + 64] = 3.0                      # one dominating key: the careful (redo) path runs in both kernels
-    x = qkv.to(torch.bfloat16).to(gu.DEV)
-    dl = torch.tensor(kv, dtype=torch.int32, device=gu.DEV)
-    ds = torch.tensor(starts, dtype=torch.int32, device=gu.DEV) if packed else None
-    outs = {}
-    for ring in (2, 3, 0, 3, 3):
-        out = torch.zeros(rows, D, dtype=torch.bfloat16, device=gu.DEV)
-        a = rt.vv_attn_args()
-        a.dtype, a.qkv, a.ld_qkv, a.out, a.ld_out, a.n_seq, a.seq_n, a.heads, a.dim = rt.VV_BF16, x.data_ptr(), 3 * D, out.data_ptr(), D, n_seq, seq_n, heads, D
-        a.kv_len = dl.data_ptr()
-        if packed:
-            a.row_start, a.total_rows = ds.data_ptr(), rows
-        a.ring = ring
-        gu.check(eng, eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()))
-        torch.cuda.synchronize()
-        if ring in outs:
-            assert torch.equal(out, outs[ring])
-        outs[ring] = out
-    if packed:
-        assert torch.equal(outs[3], outs[2]) and torch.equal(outs[0], outs[2])
-    else:                                                      # padded layout: rows past a sequence's length are computed and ignored
-        for i, L in enumerate(kv):
-            sl = slice(i * seq_n, i * seq_n + L)
-            assert torch.equal(outs[3][sl], outs[2][sl]) and torch.equal(outs[0][sl], outs[2][sl]), (i, L)
-    a.ring = 5
-    assert eng.lib.vv_attention(eng.ctx, C.byref(a), gu.stream()) == -22
-
-
 def test_attention_spiked_max(hip_tiny):
     """Online-softmax rescale branch: a key late in the sequence dominates one query row."""
     rt, gu = _imports()

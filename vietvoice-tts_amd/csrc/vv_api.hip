@@ -54,7 +54,6 @@ struct vv_ctx {
                                         // fp32 the tail no longer pays either (GEMM -3.6 ms, norms +7.1 ms per headline step,
                                         // profiles/r04/tail_fp32_notes.md).  Off, every row's arithmetic is independent of its batch neighbours.
     int chip_share = 1;                 // 2 while a call runs two lanes (vv_gemm_args.chip_share of its GEMM launches)
-    int attn_ring = 0;                  // vv_attn_args.ring of the path's attention launches: 0 auto, 2, 3 (K/V stages; same bits)
     int ring_tiles_max = 256;           // the tile-count bound of that rule (the CU count)
     int ring_tiles = 1;                 // 1 (default since round 5; same bits): N <= 1024 bf16 GEMMs whose 64 x 128 tiles are fewer than the CUs take the 64 x 64 three-stage-ring tiling (vv_gemm tile 6464)
     int pp_min_tiles = -1;              // bf16 GEMMs of the path: -1 = the launcher's own choice between the persistent 256 x 256 kernel and the 128 x 128 one
@@ -675,7 +674,6 @@ static int transformer_steps_impl(vv_ctx* c, int B, int N, const int32_t* seq_le
             t.heads = g.heads; t.dim = D; t.kv_len = L.kv_len; t.row_start = L.row_start; t.total_rows = (int)R;
             t.rope_cs_q = q_rope_attn ? L.csq : nullptr;
             t.q_scale = rope_theta > 0.f ? 1.0f / sqrtf((float)g.head_dim) : 0.f;
-            t.ring = c->attn_ring;
             Prof p(c, VV_PROF_ATTN, 4.0 * g.heads * L.sum_sq * 64, (double)es * R * 4 * D, st);
             KCHK(c, vvk_attention(&t, st, &m__));
         }
@@ -948,10 +946,6 @@ int vv_set_option(vv_ctx* c, const char* name, int value) {
     if (!strcmp(name, "split_k_tail")) {
         if (value < 0 || value > 2) return c->fail(-22, "vv_set_option: split_k_tail takes 0 (off), 1 (out-projection and FF2) or 2 (FF2 only)");
         c->split_k_tail = value; return 0;
-    }
-    if (!strcmp(name, "attn_ring")) {
-        if (value != 0 && value != 2 && value != 3) return c->fail(-22, "vv_set_option: attn_ring takes 0 (auto), 2 or 3");
-        c->attn_ring = value; return 0;
     }
     if (!strcmp(name, "ring_tiles")) { c->ring_tiles = value != 0; if (value > 1) c->ring_tiles_max = value; return 0; }
     if (!strcmp(name, "pp_min_tiles")) {

@@ -97,17 +97,11 @@ __device__ __forceinline__ AttnBlock attn_block(int nqb, int heads, int n_seq) {
 #endif
 
 // ------------------------------------------------------------------------------------ bf16
-// NST: K/V stages in LDS.  2 (the throughput form): tile T + 1 is staged in the middle of tile T and waited for with vmcnt(0) at the top
-// of tile T + 1 -- with four workgroups per CU the other workgroups cover that wait.  3 (round 5, launches of at most two workgroups per
-// CU: a single utterance's CFG branch has 208): tile T + 2 is staged in the middle of tile T and the top of a tile waits with vmcnt(4),
-// which leaves the four pieces of the younger stage in flight -- the staging latency of a tile is covered by a whole tile of work instead
-// of half of one.  Same instructions on the same values in the same order: bit-identical.
-template <int NST>
 __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
                                                            int ldo, int seq_n, int D, const int* __restrict__ kv_len_arr,
                                                            const int* __restrict__ row_start, int total_rows, int heads, int n_seq,
                                                            const float* __restrict__ rope_cs_q, float q_mul) {
-    __shared__ __attribute__((aligned(16))) char smem[NST * 16384];   // per stage: K 8 KiB | V 8 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
     const AttnBlock blk = attn_block((seq_n + 127) / 128, heads, n_seq);
     if (!blk.valid) return;
     const int head = blk.head, seq = blk.seq, qblock = blk.qb;
@@ -177,12 +171,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
     // INVARIANT (the asm form is outside hipcc's memory and waitcnt bookkeeping; nothing else guards this): stage(kt + 1, buf) must be
     // issued AFTER the barrier at the top of tile kt, and buf must be the buffer last read in tile kt - 1 -- every wave is past that
     // barrier only when it has finished tile kt - 1's PV reads.  The loads land under the explicit vmcnt(0) + barrier at the top of
-    // tile kt + 1.  Moving the call above the barrier needs a new argument; the every-row headline-size test
+    // tile kt + 1.  Moving the call above the barrier, or adding a third buffer, needs a new argument; the every-row headline-size test
     // (test_attention_headline_shape_every_row) is the regression guard.
-    // NST == 3 (the argument for the third buffer): stage(kt + 2, (kt + 2) % 3) is issued in the middle of tile kt, i.e. after the barrier at
-    // its top, into the buffer tile kt - 1 was read from (every wave is past that barrier only when its tile kt - 1 reads are consumed);
-    // at the top of tile kt a wave has issued stages <= kt + 1, four pieces each, and nothing else counts in vmcnt inside the loop, so
-    // vmcnt(4) = "stage kt has landed" for this wave, and behind the barrier for all of them; the last tile waits with vmcnt(0).
     auto stage = [&](int kt, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -217,15 +207,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
 
     const int n_tiles = (kv_len + 63) / 64;
     stage(0, 0);
-    if (NST == 3 && n_tiles > 1) stage(1, 1);
     for (int kt = 0; kt < n_tiles; ++kt) {
-        if (NST == 3 && kt + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // The next tile's K/V pieces (4 LDS-DMA instructions per wave, 60-185 cycles of issue each) are issued BETWEEN the
         // exponentials and the PV block of this tile, not here in front of the QK^T block: 705 -> 683 us at the bench shape,
         // bit-identical (profiles/r02/attn_ab_stage.txt).
-        const char* sK = smem + (NST == 3 ? kt % 3 : (kt & 1)) * 16384;
+        const char* sK = smem + (kt & 1) * 16384;
         const char* sV = sK + 8192;
 
         // ---- S'^T = K Q^T - m : scores arrive in the log2 domain (Q fragments carry log2e) and ALREADY SHIFTED by the
@@ -300,17 +288,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const bf16* __restric
         // pass per workgroup and 2 of 18 MFMAs per tile for a shift that random or trained logits never need.)
         float psum = 0.f;
         bool redo = false;
-        auto stage_ahead = [&]() {
-            if (NST == 3) { if (kt + 2 < n_tiles) stage(kt + 2, (kt + 2) % 3); }
-            else if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
-        };
 #if VV_ATTN_ABLATE == 1 || VV_ATTN_ABLATE == 3
         scores();
-        stage_ahead();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
 #else
         scores();
         psum = exps();
-        stage_ahead();
+        if (kt + 1 < n_tiles) stage(kt + 1, (kt + 1) & 1);
         redo = __any(!(psum <= RESCALE_SUM));
         if (kt == 0) redo = redo || __any(!(half_sum(psum) >= TINY_SUM));      // first tile: a row whose every weight underflowed needs its own reference
         if (redo) {
@@ -550,20 +534,10 @@ int vvk_attention(const vv_attn_args* a, hipStream_t st, const char** err) {
     const long long pairs8 = ((long long)a->heads * a->n_seq + 7) / 8;          // (sequence, head) pairs per XCD group
     if (pairs8 * nqb * 8 > 0x7fffffffLL) { *err = "attention: grid too large"; return -22; }
     const dim3 grid((unsigned)(pairs8 * nqb * 8));                               // 1-D: id % 8 = XCD group (attn_block)
-    if (a->ring != 0 && a->ring != 2 && a->ring != 3) { *err = "attention: ring must be 0 (auto), 2 or 3 K/V stages"; return -22; }
-    if (a->dtype == VV_BF16) {
-        // three K/V stages when the launch puts at most two workgroups on a CU (nothing else covers a tile's staging latency there)
-        static int n_cu = 0;
-        if (!n_cu) { hipDeviceProp_t pr; int dev = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-        const bool ring3 = a->ring == 3 || (a->ring == 0 && (long long)a->heads * a->n_seq * nqb <= 2LL * n_cu);
-        const float qm = LOG2E * (a->q_scale > 0.f ? a->q_scale : 1.0f);
-        if (ring3)
-            attn_bf16_kernel<3><<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                                      a->heads, a->n_seq, a->rope_cs_q, qm);
-        else
-            attn_bf16_kernel<2><<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
-                                                      a->heads, a->n_seq, a->rope_cs_q, qm);
-    } else
+    if (a->dtype == VV_BF16)
+        attn_bf16_kernel<<<grid, 256, 0, st>>>((const bf16*)a->qkv, a->ld_qkv, (bf16*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start, total_rows,
+                                               a->heads, a->n_seq, a->rope_cs_q, LOG2E * (a->q_scale > 0.f ? a->q_scale : 1.0f));
+    else
         attn_f32_kernel<<<grid, 256, 0, st>>>((const float*)a->qkv, a->ld_qkv, (float*)a->out, a->ld_out, a->seq_n, a->dim, a->kv_len, a->row_start,
                                               a->heads, a->n_seq);
     hipError_t he = hipGetLastError();

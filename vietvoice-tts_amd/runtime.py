@@ -59,8 +59,7 @@ class vv_gemm_args(C.Structure):
 class vv_attn_args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("qkv", C.c_void_p), ("ld_qkv", C.c_int32), ("out", C.c_void_p), ("ld_out", C.c_int32),
                 ("n_seq", C.c_int32), ("seq_n", C.c_int32), ("heads", C.c_int32), ("dim", C.c_int32), ("kv_len", C.c_void_p),
-                ("row_start", C.c_void_p), ("total_rows", C.c_int32), ("q_scale", C.c_float), ("rope_cs_q", C.c_void_p),
-                ("ring", C.c_int32)]
+                ("row_start", C.c_void_p), ("total_rows", C.c_int32), ("q_scale", C.c_float), ("rope_cs_q", C.c_void_p)]
 
 
 class vv_ln_args(C.Structure):
