@@ -338,7 +338,8 @@ VV_API int vv_cfg_euler(vv_ctx* ctx, float* x, const float* pred, int ldp, int B
 /* pcm = the clips' interleaved little-endian signed PCM bytes, back to back (each clip 4-byte aligned); desc = n_clips x 8 int64
  * (device): {byte offset, sample width 1|2|4, channels, n_frames, src_rate / g, dst_rate / g, out offset (floats), n_out} with
  * g = gcd(src_rate, dst_rate) and n_out = (n_frames - 1) * (dst_rate / g) / (src_rate / g) + 1 (= n_frames at equal rates).
- * out[out offset + m] = float32 of the mono sample m at the destination rate.  max_out = the largest n_out. */
+ * out[out offset + m] = float32 of the mono sample m at the destination rate.  max_out = the largest n_out.  The rows live in device
+ * memory, so the library cannot check them: the CALLER validates them against the two buffers before the call (runtime.HipSynth.ingest_pcm does). */
 VV_API int vv_ingest_pcm(vv_ctx* ctx, const void* pcm, const int64_t* desc, int n_clips, int64_t max_out, float* out, void* stream);
 /* opt-in, NOT the reference's arithmetic: polyphase FIR resampler y[n] = sum_i x[i] * taps[(n + skip) * down - i * up],
  * f64 accumulate, f32 out.  taps = host-designed low-pass already scaled by `up` (f64, device). */

@@ -51,6 +51,7 @@ class BatchingFrontend:
         self._serial = 0
         self._serial_lock = threading.Lock()
         self._closed = False           # close() has been called: submit() refuses (set under _serial_lock)
+        self._stage_down = False       # the collecting stage has ended (normally or not): nothing will take a request off the queue any more
         self._closing = False          # the close() sentinel has been taken off the request queue
         self.batches_run = 0
         self.requests_done = 0
@@ -71,7 +72,7 @@ class BatchingFrontend:
         ``serial`` fixes the request's noise stream (default: arrival counter)."""
         fut: Future = Future()
         with self._serial_lock:           # close() raises `_closed` under the same lock: a request is either queued in front of the
-            if self._closed:              # sentinel (and served) or refused here -- never orphaned behind it
+            if self._closed or self._stage_down:      # sentinel (and served) or refused here -- never orphaned behind it
                 fut.set_exception(RuntimeError("Speech synthesis failed: the batching front end is closed"))
                 return fut
             if serial is None:
@@ -189,6 +190,9 @@ class BatchingFrontend:
             if not isinstance(e, Exception):
                 raise
         finally:
+            with self._serial_lock:        # from here on submit() refuses; whatever raced in before is failed, not stranded
+                self._stage_down = True
+            self._drain_requests("the batching front end has stopped")
             self._ready.put(None)          # whatever happened here, the stages behind must see the end of the stream
 
     def _prep_body(self):
@@ -291,14 +295,25 @@ class BatchingFrontend:
 
     # ------------------------------------------------------------------ overlap=False: the three stages in order on one thread
     def _serial_loop(self):
-        while True:
-            batch = self._collect()
-            if batch is None:
-                break
-            if not batch.flat:
-                continue
-            try:
-                waves, err = self._run_batch(batch), None
-            except Exception as e:        # noqa: BLE001
-                waves, err = None, e
-            self._finish(batch, waves, err)
+        batch = None
+        try:
+            while True:
+                batch = self._collect()
+                if batch is None:
+                    break
+                if not batch.flat:
+                    continue
+                try:
+                    waves, err = self._run_batch(batch), None
+                except Exception as e:    # noqa: BLE001
+                    waves, err = None, e
+                self._finish(batch, waves, err)
+        except BaseException as e:        # noqa: BLE001  (same promise as the pipelined stages: no Future left pending)
+            self._fail(batch, e)
+            self._drain_requests(e)
+            if not isinstance(e, Exception):
+                raise
+        finally:
+            with self._serial_lock:
+                self._stage_down = True
+            self._drain_requests("the batching front end has stopped")

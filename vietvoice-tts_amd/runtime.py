@@ -273,11 +273,11 @@ class HipSynth:
         t, dt = time_grid(nfe_step, self.spec.sway_coef)
         sinus = pack.time_sinus_table(self.spec, t).contiguous()
         dtc = dt.contiguous()
-        with torch.cuda.device(self.device):
+        with self._lock, torch.cuda.device(self.device):          # under the engine lock: no step call or graph replay runs across the change
             self._check(self.lib.vv_set_time_grid(self.ctx, sinus.data_ptr(), dtc.data_ptr(), int(t.numel()), self._stream()))
-        self.nfe_step = nfe_step
-        self.n_steps = int(t.numel())
-        self.grid_generation += 1        # vv_set_time_grid frees and reallocates the tables a captured step graph points into
+            self.nfe_step = nfe_step
+            self.n_steps = int(t.numel())
+            self.grid_generation += 1    # vv_set_time_grid frees and reallocates the tables a captured step graph points into
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, audio: torch.Tensor, audio_len: torch.Tensor, text_ids: torch.Tensor, text_len: torch.Tensor,
@@ -402,34 +402,53 @@ class HipSynth:
                                                   y.data_ptr(), n_out, self._stream()))
         return y
 
-    def ingest_pcm(self, pcm: torch.Tensor, desc: torch.Tensor, max_out: int, total_out: int) -> torch.Tensor:
-        """pcm uint8 [bytes] (clips' interleaved PCM back to back) and desc int64 [n, 8] on the device (include/vvtts.h) ->
-        f32 [total_out]: mono samples at the destination rate (audioop.tomono + audioop.ratecv arithmetic)."""
-        assert pcm.is_cuda and pcm.dtype == torch.uint8 and pcm.is_contiguous() and desc.is_cuda and desc.dtype == torch.int64 and desc.is_contiguous()
-        assert desc.dim() == 2 and desc.shape[1] == 8
+    def ingest_pcm(self, pcm: torch.Tensor, desc, total_out: int) -> torch.Tensor:
+        """pcm uint8 [bytes] on the device (the clips' interleaved PCM back to back) and desc = HOST rows of 8 ints per clip
+        (include/vvtts.h: byte offset, width, channels, n_frames, src / g, dst / g, out offset, n_out) -> f32 [total_out]: mono samples at
+        the destination rate (audioop.tomono + audioop.ratecv arithmetic).  The rows are validated here, on the host, before anything
+        is launched: the kernel indexes the byte buffer by them."""
+        assert pcm.is_cuda and pcm.dtype == torch.uint8 and pcm.is_contiguous()
+        rows = [[int(v) for v in r] for r in desc]
+        if not rows:
+            raise ValueError("ingest_pcm: no clips")
+        for r in rows:
+            if len(r) != 8:
+                raise ValueError("ingest_pcm: a descriptor row has 8 entries")
+            off, width, ch, n_frames, I, O, out_off, n_out = r
+            want = n_frames if I == O else ((n_frames - 1) * O // I + 1 if n_frames > 0 else 0)
+            if (width not in (1, 2, 4) or ch < 1 or n_frames < 1 or I < 1 or O < 1 or off < 0 or off % width or n_out != want or n_out < 1
+                    or off + n_frames * ch * width > pcm.numel() or out_off < 0 or out_off + n_out > total_out):
+                raise ValueError(f"ingest_pcm: descriptor row {r} does not fit the buffers ({pcm.numel()} PCM bytes, {total_out} output samples)")
         y = torch.empty((total_out,), dtype=torch.float32, device=self.device)
+        d = torch.tensor(rows, dtype=torch.int64).to(self.device)
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.vv_ingest_pcm(self.ctx, pcm.data_ptr(), desc.data_ptr(), desc.shape[0], max_out, y.data_ptr(), self._stream()))
+            self._check(self.lib.vv_ingest_pcm(self.ctx, pcm.data_ptr(), d.data_ptr(), len(rows), max(r[7] for r in rows), y.data_ptr(), self._stream()))
         return y
 
     def normalize_clips(self, x: torch.Tensor, offsets: torch.Tensor, max_len: int = 0) -> torch.Tensor:
         """x f32 [total] = clips back to back, offsets int64 [n+1] (device) -> int16 [total] (DC removed, peak 29491);
-        max_len = the longest clip when the caller knows it (else the total is taken as the bound)."""
+        max_len = the longest clip when the caller knows it (else it is read back from the offsets)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and offsets.is_cuda and offsets.dtype == torch.int64
         n = offsets.numel() - 1
+        if not max_len:
+            oh = offsets.cpu()
+            if int(oh[0]) != 0 or int(oh[-1]) != x.numel() or bool((oh[1:] < oh[:-1]).any()):
+                raise ValueError("normalize_clips: offsets must run from 0 to x.numel(), non-decreasing")
+            max_len = int((oh[1:] - oh[:-1]).max())
         out = torch.empty((x.numel(),), dtype=torch.int16, device=self.device)
         scratch = torch.empty((int(self.lib.vv_normalize_scratch_bytes(n, x.numel())),), dtype=torch.uint8, device=self.device)
         with self._lock, torch.cuda.device(self.device):
-            self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, int(max_len) or x.numel(), scratch.data_ptr(),
+            self._check(self.lib.vv_normalize_clips(self.ctx, x.data_ptr(), offsets.data_ptr(), n, int(max_len), scratch.data_ptr(),
                                                     out.data_ptr(), self._stream()))
         return out
 
     def set_rope_theta(self, theta: float):
         """theta > 1: the rope tables of this engine are the standard ones of that base, the bf16 QKV epilogue computes the angles;
         0: the tables are read (vv_set_rope_theta)."""
-        self._check(self.lib.vv_set_rope_theta(self.ctx, float(theta)))
-        self._rope_theta = float(theta)
-        self.grid_generation += 1
+        with self._lock:
+            self._check(self.lib.vv_set_rope_theta(self.ctx, float(theta)))
+            self._rope_theta = float(theta)
+            self.grid_generation += 1
 
     @contextlib.contextmanager
     def reading_rope_tables(self):
@@ -446,8 +465,9 @@ class HipSynth:
 
     def set_option(self, name: str, value: int):
         """Context switches of the C ABI (vv_set_option), e.g. ``fuse_mrf`` 0/1."""
-        self._check(self.lib.vv_set_option(self.ctx, name.encode(), int(value)))
-        self.grid_generation += 1
+        with self._lock:
+            self._check(self.lib.vv_set_option(self.ctx, name.encode(), int(value)))
+            self.grid_generation += 1
 
     # ------------------------------------------------------------------ profiling
     def prof_enable(self, on: bool):
@@ -562,10 +582,10 @@ class GraphedSteps:
     def __call__(self, noise: torch.Tensor, pre: Dict[str, torch.Tensor]):
         """noise [B,N,n_mel] and ``pre`` (HipSynth.preprocess of the same batch) -> (x, pcm, pcm_len): views of the static buffers,
         valid until the next call."""
-        if self.stale():
-            raise RuntimeError("captured Euler-step graph is stale: the engine's time grid, rope mode or an option changed after the "
-                               "capture (set_nfe / set_rope_theta / set_option); capture again with HipSynth.capture_steps")
-        with self.eng._lock:
+        with self.eng._lock:                             # the setters take the same lock: the check and the replay see one state
+            if self.stale():
+                raise RuntimeError("captured Euler-step graph is stale: the engine's time grid, rope mode or an option changed after the "
+                                   "capture (set_nfe / set_rope_theta / set_option); capture again with HipSynth.capture_steps")
             self.x.copy_(noise)
             self.cat.copy_(pre["cat_mel_text"])
             self.cat_drop.copy_(pre["cat_mel_text_drop"])

@@ -25,7 +25,7 @@ from typing import Dict, List, Tuple, Union
 
 import numpy as np
 
-from .core.audio_processor import AudioProcessor
+from .core.audio_processor import AudioProcessor, ratecv_len, tomono
 
 
 def resample_design(src: int, dst: int) -> Tuple[np.ndarray, int, int, int]:
@@ -124,9 +124,7 @@ class VoiceBank:
     def _ingest_ratecv(self, decoded, dev):
         """One vv_ingest_pcm launch for all clips: interleaved PCM bytes back to back (4-byte aligned) + descriptor rows."""
         import torch
-        from .core.audio_processor import ratecv_len
         parts, desc, pos, out_pos = [], [], 0, 0
-        from .core.audio_processor import tomono
         for frames, width, rate in decoded:
             if frames.shape[1] > 2:
                 tomono(frames)                    # range check only (OverflowError like the reference); the mix itself runs on the device
@@ -139,9 +137,7 @@ class VoiceBank:
             pos += len(raw) + pad
             out_pos += n_out
         buf = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).to(dev)
-        lens = [d[7] for d in desc]
-        x = self.synth.ingest_pcm(buf, torch.tensor(desc, dtype=torch.int64).to(dev), max(lens), out_pos)
-        return x, lens
+        return self.synth.ingest_pcm(buf, desc, out_pos), [d[7] for d in desc]
 
     def _ingest_polyphase(self, decoded, dev):
         import torch
