@@ -50,12 +50,15 @@ __device__ __forceinline__ long long mono_frame(const T* __restrict__ p, long lo
 
 template <typename T>
 __device__ __forceinline__ float ingest_one(const T* __restrict__ p, int ch, long long n_frames, long long I, long long O, long long m) {
-    if (I == O) return (float)mono_frame(p, m, ch);
+    const long long last = n_frames - 1;                                             // every frame index is clamped: a wrong n_out cannot read past the clip
+    if (I == O) return (float)mono_frame(p, m < last ? m : last, ch);
     const int shift = 32 - 8 * (int)sizeof(T);
-    const long long n1 = (m * I + O - 1) / O;                                        // the frame ratecv calls cur_i
+    const long long to32 = 1LL << shift;                                             // GETSAMPLE32: the sample at the top of a 32-bit word
+    long long n1 = (m * I + O - 1) / O;                                              // the frame ratecv calls cur_i
     const long long d = n1 * O - m * I;                                              // in [0, O)
-    const double cur = (double)(mono_frame(p, n1, ch) << shift);
-    const double prev = n1 > 0 ? (double)(mono_frame(p, n1 - 1, ch) << shift) : 0.0; // ratecv starts with prev_i = cur_i = 0
+    if (n1 > last) n1 = last;
+    const double cur = (double)(mono_frame(p, n1, ch) * to32);
+    const double prev = n1 > 0 ? (double)(mono_frame(p, n1 - 1, ch) * to32) : 0.0;   // ratecv starts with prev_i = cur_i = 0
     // cur_o = (int)((prev_i * d + cur_i * (outrate - d)) / outrate), every operation rounded separately (no fma contraction)
     const double v = __ddiv_rn(__dadd_rn(__dmul_rn(prev, (double)d), __dmul_rn(cur, (double)(O - d))), (double)O);
     return (float)(T)((long long)v >> shift);
