@@ -580,9 +580,10 @@ def main():
         "timed_region": ("host (pinned) int16 clips / ids / noise -> H2D -> preprocess + Euler steps + vocoder -> int16 PCM D2H to pinned host memory (--pcie; SURVEY 8d)"
                          if a.pcie else "inputs (int16 clips, ids, noise) and int16 PCM resident in HBM: preprocess + Euler steps + vocoder; the PCIe-inclusive "
                                         "rate of the same step is in `pcie_inclusive`"),
-        "hbm_target_note": "north_star's '>= 40 % of HBM roofline on the vocoder kernel' applies to the memory-bound vocoder kernels (K13 conv_post+tanh+int16, "
-                           "K10 frame slice): every MRF / upsample conv has arithmetic intensity 32-450 flop/B, above the f32-MFMA ridge (~20) and around the "
-                           "ridge of the six-term bf16 form (~52), and is reported against its matrix roof with the HBM side beside it (SURVEY 7 / 8d)",
+        "hbm_target_note": "north_star's '>= 40 % of HBM roofline on the vocoder kernel': met by the kernels SURVEY 8(a) puts on the HBM roof that are "
+                           "memory-bound in practice -- K13 conv_post+tanh+int16 (0.70-0.75) and the x2 up-sampler of stage 3 (0.41-0.44, round 5); stage 2 "
+                           "(arithmetic intensity 64 flop/B, above the ~52 ridge of the six-term bf16 form) and every MRF conv (43-450 flop/B) are reported "
+                           "against their matrix roof with the HBM side beside it: `vocoder_stages` (SURVEY 7 / 8d)",
         "vocoder_arith": ("fp32 in / out / accumulate; every product a*w taken as the six bf16 piece products >= 2^-16 |a w| of exact 3-way splits a = h+m+l, "
                           "w = h+m+l (v_mfma_f32_32x32x16_bf16, vv_vocoder_x3.hip): fp32 fidelity -- waveform max |err| vs the float64 oracle 7.6e-7 against "
                           "7.4e-7 for v_mfma_f32_32x32x2_f32 (tests/test_fullsize_gpu.py)") if voc_x3 else "fp32 (v_mfma_f32_32x32x2_f32)",
