@@ -263,6 +263,8 @@ __global__ __launch_bounds__(CFG == 2 ? 1024 : (CFG == 1 ? 512 : 256), CFG == 2 
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPA + PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");          // compiler fence: no LDS read of this K-tile may be scheduled above the barrier (the last two
+                                                    // K-tiles issue no stage3 asm behind it to do that job)
             if (kt + 2 < nk) stage3(kt + 2, (kt + 2) % 3);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
